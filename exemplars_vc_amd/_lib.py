@@ -1,0 +1,87 @@
+"""ctypes binding of libevc_hip.so (the C ABI declared in include/evc.h).
+
+The product path has no CPU fallback: if the library is missing or cannot be loaded,
+`lib()` raises and every solver entry point fails with it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libevc_hip.so")
+
+F64, F32 = 0, 1
+FRAME_MAJOR, BIN_MAJOR = 0, 1
+EPS_ADD, EPS_ZERO_REPLACE, EPS_NONE, EPS_CLAMP = 0, 1, 2, 3
+ALGO_GRAM, ALGO_FACTORED, ALGO_LITERAL, ALGO_AUTO = 0, 1, 2, 3
+INIT_GIVEN, INIT_SKLEARN, INIT_CONST = 0, 1, 2
+STOP_NONE, STOP_SKLEARN, STOP_PYMF = 0, 1, 2
+
+# every symbol include/evc.h declares; tests check that the library exports all of them
+SYMBOLS = ("evc_version", "evc_strerror", "evc_device_count", "evc_workspace_bytes",
+           "evc_nmf_solve", "evc_synthesize", "evc_residual")
+
+
+class SolveOpts(C.Structure):
+    """Mirror of `evc_solve_opts` (include/evc.h)."""
+    _fields_ = [
+        ("struct_bytes", C.c_int), ("dtype", C.c_int), ("layout", C.c_int), ("algo", C.c_int),
+        ("iters", C.c_int), ("eps_mode", C.c_int), ("init_mode", C.c_int),
+        ("check_every", C.c_int), ("stop_rule", C.c_int), ("reserved", C.c_int),
+        ("eps", C.c_double), ("l1", C.c_double), ("tol", C.c_double), ("init_value", C.c_double),
+    ]
+
+
+class EvcError(RuntimeError):
+    def __init__(self, status, what):
+        super().__init__(f"{what}: {strerror(status)} (status {status})")
+        self.status = status
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `python -m exemplars_vc_amd.csrc.build` "
+            "(hipcc, gfx950).  exemplars_vc_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.evc_version.restype = C.c_int
+    L.evc_strerror.restype = C.c_char_p
+    L.evc_strerror.argtypes = [C.c_int]
+    L.evc_device_count.restype = C.c_int
+    L.evc_workspace_bytes.restype = C.c_size_t
+    L.evc_workspace_bytes.argtypes = [C.c_int] * 6
+    L.evc_nmf_solve.restype = C.c_int
+    L.evc_nmf_solve.argtypes = [
+        C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,      # A, X, H
+        C.c_int, C.c_int, C.c_int,                                          # M, N, T
+        C.POINTER(C.c_int), C.c_int,                                        # utt_offsets, n_utt
+        C.POINTER(SolveOpts),
+        C.c_void_p, C.c_size_t,                                             # workspace
+        C.POINTER(C.c_int), C.POINTER(C.c_double),                          # n_iter_out, err_out
+        C.c_void_p,                                                         # stream
+    ]
+    L.evc_synthesize.restype = C.c_int
+    L.evc_synthesize.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                 C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.evc_residual.restype = C.c_int
+    L.evc_residual.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                               C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                               C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    _lib = L
+    return L
+
+
+def strerror(status: int) -> str:
+    return lib().evc_strerror(int(status)).decode()
+
+
+def check(status: int, what: str):
+    if status != 0:
+        raise EvcError(status, what)

@@ -1,0 +1,7 @@
+"""Drop-in mirrors of the reference's call surfaces for the activation-solve path.
+
+  factorize  - `_factorize` / `convert` of 04_align_n_nmf.py (the scikit-learn based live path)
+  pymf       - `pymf.nmf.NMF(data, num_bases).factorize(compute_w=False)`
+  nmf_tool   - `nmf_tool.nmf.NMF(...).fit_transform(X, r, initW=True, givenW=A)`
+"""
+from . import factorize, nmf_tool, pymf  # noqa: F401

@@ -1,0 +1,320 @@
+// C ABI of libevc_hip.so (see include/evc.h): argument checking, workspace carving and the
+// launch sequence of one activation solve.  No allocation, no global state, no exceptions.
+#include "evc_internal.h"
+
+#include <math.h>
+#include <string.h>
+
+using namespace evc;
+
+namespace {
+
+enum { ST_OK = 0, ST_BADARG = -1, ST_WORKSPACE = -2, ST_UNSUPPORTED = -3 };
+
+struct Carver {
+    char* base;
+    size_t off;
+    template <typename U> U* take(size_t count) {
+        off = (off + 255) & ~size_t(255);
+        U* p = base ? reinterpret_cast<U*>(base + off) : nullptr;
+        off += count * sizeof(U);
+        return p;
+    }
+};
+
+struct Dims {
+    int M, N, T_, n_utt;
+    int Mk, Mj, Np, Tp;
+};
+
+Dims make_dims(int M, int N, int T_, int n_utt) {
+    Dims d;
+    d.M = M; d.N = N; d.T_ = T_; d.n_utt = n_utt;
+    d.Mk = round_up(M, 16);
+    d.Mj = round_up(M, 64);
+    d.Np = round_up(N, 128);
+    d.Tp = round_up(T_, 128);
+    return d;
+}
+
+template <typename T> struct Workspace {
+    T *At, *Am, *Xt, *H0, *H1, *Pt, *G, *Vt;
+    double* err2;
+    UttState u;
+    void* fused;
+    size_t bytes;
+};
+
+int n_slots_for(int iters, int check_every) { return 1 + (check_every > 0 ? iters / check_every : 0); }
+
+template <typename T>
+Workspace<T> carve(void* base, const Dims& d, int algo, int n_slots, bool with_fused) {
+    Workspace<T> w;
+    Carver c{static_cast<char*>(base), 0};
+    const bool gram = (algo == EVC_ALGO_GRAM || algo == EVC_ALGO_LITERAL);
+    w.At = c.take<T>((size_t)d.Np * d.Mk);
+    w.Am = c.take<T>((size_t)d.Mj * d.Np);
+    w.Xt = c.take<T>((size_t)d.Tp * d.Mk);
+    w.H0 = c.take<T>((size_t)d.Tp * d.Np);
+    w.Pt = c.take<T>((size_t)d.Tp * d.Np);
+    w.Vt = c.take<T>((size_t)d.Tp * d.Mj);
+    w.H1 = gram ? c.take<T>((size_t)d.Tp * d.Np) : nullptr;
+    w.G = gram ? c.take<T>((size_t)d.Np * d.Np) : nullptr;
+    w.err2 = c.take<double>(d.Tp);
+    w.u.frame_utt = c.take<int>(d.Tp);
+    w.u.offsets = c.take<int>(d.n_utt + 1);
+    w.u.active = c.take<int>(d.n_utt);
+    w.u.n_iter = c.take<int>(d.n_utt);
+    w.u.err_init = c.take<double>(d.n_utt);
+    w.u.err_prev = c.take<double>(d.n_utt);
+    w.u.h0 = c.take<double>(d.n_utt);
+    w.u.trace = c.take<double>((size_t)d.n_utt * n_slots);
+    w.u.n_slots = n_slots;
+    w.fused = nullptr;
+    (void)with_fused;
+    w.bytes = (c.off + 255) & ~size_t(255);
+    return w;
+}
+
+#define HIP_TRY(expr)                              \
+    do {                                           \
+        hipError_t e__ = (expr);                   \
+        if (e__ != hipSuccess) return (int)e__;    \
+    } while (0)
+
+// The worst-case slot count is bounded by iters+1; evc_workspace_bytes has no iters argument,
+// so the trace region is sized for MAX_SLOTS checks and evc_nmf_solve rejects more.
+constexpr int MAX_SLOTS = 4097;
+
+template <typename T>
+int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int ldh, int M, int N,
+                int T_, const int* utt_offsets, int n_utt, const evc_solve_opts& o, void* ws,
+                size_t ws_bytes, int* n_iter_out, double* err_out, hipStream_t s) {
+    const T* A = static_cast<const T*>(A_);
+    const T* X = static_cast<const T*>(X_);
+    T* H = static_cast<T*>(H_);
+    const Dims d = make_dims(M, N, T_, n_utt);
+    int algo = o.algo == EVC_ALGO_AUTO ? EVC_ALGO_FACTORED : o.algo;
+    const int n_slots = n_slots_for(o.iters, o.check_every);
+    if (n_slots > MAX_SLOTS) return ST_UNSUPPORTED;
+    Workspace<T> w = carve<T>(ws, d, algo, MAX_SLOTS, false);
+    if (w.bytes > ws_bytes) return ST_WORKSPACE;
+    w.u.n_slots = n_slots;
+    const bool fm = (o.layout == EVC_FRAME_MAJOR);
+
+    // ---- utterances ----
+    if (utt_offsets)
+        HIP_TRY(hipMemcpyAsync(w.u.offsets, utt_offsets, sizeof(int) * (n_utt + 1), hipMemcpyHostToDevice, s));
+    else
+        HIP_TRY(utt_single(w.u, T_, s));
+    HIP_TRY(utt_setup(w.u, n_utt, T_, d.Tp, o.iters, s));
+
+    // ---- import the caller's matrices into zero-padded frames-as-rows workspace arrays ----
+    // At[n][m], Am[m][n], Xt[t][m], Ht[t][n]
+    HIP_TRY(copy2d<T>(A, lda, N, M, fm ? 0 : 1, w.At, d.Mk, d.Np, d.Mk, 0, s));
+    HIP_TRY(copy2d<T>(A, lda, M, N, fm ? 1 : 0, w.Am, d.Np, d.Mj, d.Np, 0, s));
+    HIP_TRY(copy2d<T>(X, ldx, T_, M, fm ? 0 : 1, w.Xt, d.Mk, d.Tp, d.Mk, 0, s));
+    if (o.init_mode == EVC_INIT_GIVEN) {
+        HIP_TRY(copy2d<T>(H, ldh, T_, N, fm ? 0 : 1, w.H0, d.Np, d.Tp, d.Np, 0, s));
+    } else {
+        if (o.init_mode == EVC_INIT_SKLEARN) HIP_TRY(utt_sklearn_h0<T>(w.Xt, d.Mk, M, N, w.u, n_utt, s));
+        else HIP_TRY(utt_const_h0(w.u, n_utt, o.init_value, s));
+        HIP_TRY(fill_h0<T>(w.H0, d.Np, d.Tp, N, T_, w.u, s));
+    }
+
+    // ---- numerator (and Gram matrix) ----
+    const bool gram = (algo == EVC_ALGO_GRAM || algo == EVC_ALGO_LITERAL);
+    if (gram) HIP_TRY(gemm_nt<T>(w.At, d.Mk, w.At, d.Mk, w.G, d.Np, d.Np, d.Np, d.Mk, s));
+    HIP_TRY(gemm_nt<T>(w.Xt, d.Mk, w.At, d.Mk, w.Pt, d.Np, d.Tp, d.Np, d.Mk, s));
+
+    T* Hc = w.H0;       // current activations
+    T* Hn = w.H1;       // ping-pong partner (GRAM only)
+    bool v_valid = false;
+
+    auto residual_check = [&](int c) -> int {
+        if (!v_valid) HIP_TRY(gemm_nt<T>(Hc, d.Np, w.Am, d.Np, w.Vt, d.Mj, d.Tp, d.Mj, d.Np, s));
+        v_valid = true;
+        HIP_TRY(frame_err2<T>(w.Xt, d.Mk, w.Vt, d.Mj, M, T_, w.err2, s));
+        HIP_TRY(utt_check(w.err2, w.u, n_utt, c, o.check_every, o.stop_rule, o.tol, s));
+        return 0;
+    };
+
+    if (o.check_every > 0 && o.stop_rule == EVC_STOP_SKLEARN) {
+        int st = residual_check(0);     // error_at_init, sklearn _nmf.py:827
+        if (st) return st;
+    }
+
+    MuEpilogue<T> ep;
+    ep.P = w.Pt; ep.frame_utt = w.u.frame_utt; ep.active = w.u.active; ep.ldh = d.Np;
+    ep.N = N; ep.T_ = T_; ep.eps_mode = o.eps_mode; ep.eps = (T)o.eps; ep.l1 = (T)o.l1;
+
+    for (int it = 1; it <= o.iters; ++it) {
+        if (algo == EVC_ALGO_LITERAL) {   // pymf nmf.py:68-69 recomputes both every iteration
+            HIP_TRY(gemm_nt<T>(w.At, d.Mk, w.At, d.Mk, w.G, d.Np, d.Np, d.Np, d.Mk, s));
+            HIP_TRY(gemm_nt<T>(w.Xt, d.Mk, w.At, d.Mk, w.Pt, d.Np, d.Tp, d.Np, d.Mk, s));
+        }
+        if (gram) {
+            ep.Hin = Hc;                  // H' = mu(H, P, H G^T)   (G symmetric)
+            HIP_TRY(gemm_nt_mu<T>(Hc, d.Np, w.G, d.Np, Hn, d.Tp, d.Np, d.Np, ep, s));
+            T* tmp = Hc; Hc = Hn; Hn = tmp;
+        } else {
+            if (!v_valid) HIP_TRY(gemm_nt<T>(Hc, d.Np, w.Am, d.Np, w.Vt, d.Mj, d.Tp, d.Mj, d.Np, s));
+            ep.Hin = Hc;                  // H' = mu(H, P, V At^T), V = H Am^T ; in place
+            HIP_TRY(gemm_nt_mu<T>(w.Vt, d.Mj, w.At, d.Mk, Hc, d.Tp, d.Np, d.Mk, ep, s));
+        }
+        v_valid = false;
+        if (o.check_every > 0 && it % o.check_every == 0) {
+            int st = residual_check(it / o.check_every);
+            if (st) return st;
+        }
+    }
+
+    // ---- export ----
+    HIP_TRY(copy2d<T>(Hc, d.Np, T_, N, 0, H, ldh, T_, N, fm ? 0 : 1, s));
+    if (n_iter_out || err_out) {
+        if (n_iter_out)
+            HIP_TRY(hipMemcpyAsync(n_iter_out, w.u.n_iter, sizeof(int) * n_utt, hipMemcpyDeviceToHost, s));
+        if (err_out)
+            HIP_TRY(hipMemcpyAsync(err_out, w.u.trace, sizeof(double) * (size_t)n_utt * n_slots,
+                                   hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return ST_OK;
+}
+
+template <typename T> size_t workspace_typed(int M, int N, int T_, int n_utt, int algo) {
+    const Dims d = make_dims(M, N, T_, n_utt);
+    return carve<T>(nullptr, d, algo == EVC_ALGO_AUTO ? EVC_ALGO_FACTORED : algo, MAX_SLOTS, true).bytes;
+}
+
+bool bad_ld(int layout, int ld, int rows_fm, int cols_fm) {
+    // FRAME_MAJOR: rows_fm x cols_fm with ld >= cols_fm; BIN_MAJOR: the transpose
+    return layout == EVC_FRAME_MAJOR ? ld < cols_fm : ld < rows_fm;
+}
+
+}  // namespace
+
+extern "C" {
+
+int evc_version(void) { return EVC_VERSION; }
+
+const char* evc_strerror(int status) {
+    switch (status) {
+        case ST_OK: return "ok";
+        case ST_BADARG: return "invalid argument";
+        case ST_WORKSPACE: return "workspace too small (see evc_workspace_bytes)";
+        case ST_UNSUPPORTED: return "unsupported option combination";
+        default: break;
+    }
+    if (status > 0) return hipGetErrorString((hipError_t)status);
+    return "unknown status";
+}
+
+int evc_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    return e == hipSuccess ? n : -(int)e;
+}
+
+size_t evc_workspace_bytes(int M, int N, int T, int n_utt, int dtype, int algo) {
+    if (M < 0 || N < 0 || T < 0 || n_utt < 1) return 0;
+    if (algo < EVC_ALGO_GRAM || algo > EVC_ALGO_AUTO) return 0;
+    if (dtype == EVC_F64) return workspace_typed<double>(M, N, T, n_utt, algo);
+    if (dtype == EVC_F32) return workspace_typed<float>(M, N, T, n_utt, algo);
+    return 0;
+}
+
+int evc_nmf_solve(const void* A, int lda, const void* X, int ldx, void* H, int ldh, int M, int N,
+                  int T, const int* utt_offsets, int n_utt, const evc_solve_opts* opts,
+                  void* workspace, size_t workspace_bytes, int* n_iter_out, double* err_out,
+                  evc_stream_t stream) {
+    if (!opts || opts->struct_bytes != (int)sizeof(evc_solve_opts)) return ST_BADARG;
+    const evc_solve_opts& o = *opts;
+    if (M < 1 || N < 1 || T < 0 || n_utt < 1 || o.iters < 0) return ST_BADARG;
+    if (o.dtype != EVC_F64 && o.dtype != EVC_F32) return ST_BADARG;
+    if (o.layout != EVC_FRAME_MAJOR && o.layout != EVC_BIN_MAJOR) return ST_BADARG;
+    if (o.algo < EVC_ALGO_GRAM || o.algo > EVC_ALGO_AUTO) return ST_BADARG;
+    if (o.eps_mode < EVC_EPS_ADD || o.eps_mode > EVC_EPS_CLAMP) return ST_BADARG;
+    if (o.init_mode < EVC_INIT_GIVEN || o.init_mode > EVC_INIT_CONST) return ST_BADARG;
+    if (o.stop_rule < EVC_STOP_NONE || o.stop_rule > EVC_STOP_PYMF) return ST_BADARG;
+    if (o.check_every < 0) return ST_BADARG;
+    if (o.stop_rule != EVC_STOP_NONE && o.check_every == 0) return ST_BADARG;
+    if (!(o.l1 >= 0.0)) return ST_BADARG;
+    if (T == 0) {
+        if (n_iter_out) for (int i = 0; i < n_utt; ++i) n_iter_out[i] = 0;
+        return ST_OK;
+    }
+    if (!A || !X || !H || !workspace) return ST_BADARG;
+    if (bad_ld(o.layout, lda, N, M) || bad_ld(o.layout, ldx, T, M) || bad_ld(o.layout, ldh, T, N))
+        return ST_BADARG;
+    if (utt_offsets) {
+        if (utt_offsets[0] != 0 || utt_offsets[n_utt] != T) return ST_BADARG;
+        for (int i = 0; i < n_utt; ++i)
+            if (utt_offsets[i + 1] < utt_offsets[i]) return ST_BADARG;
+    } else if (n_utt != 1) {
+        return ST_BADARG;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (o.dtype == EVC_F64)
+        return solve_typed<double>(A, lda, X, ldx, H, ldh, M, N, T, utt_offsets, n_utt, o, workspace,
+                                   workspace_bytes, n_iter_out, err_out, s);
+    return solve_typed<float>(A, lda, X, ldx, H, ldh, M, N, T, utt_offsets, n_utt, o, workspace,
+                              workspace_bytes, n_iter_out, err_out, s);
+}
+
+int evc_synthesize(const void* B, int ldb, const void* H, int ldh, void* Y, int ldy, int Mb, int N,
+                   int T, int layout, int dtype, evc_stream_t stream) {
+    if (Mb < 1 || N < 0 || T < 0) return ST_BADARG;
+    if (layout != EVC_FRAME_MAJOR && layout != EVC_BIN_MAJOR) return ST_BADARG;
+    if (dtype != EVC_F64 && dtype != EVC_F32) return ST_BADARG;
+    if (T == 0) return ST_OK;
+    if (!Y || (N > 0 && (!B || !H))) return ST_BADARG;
+    if (bad_ld(layout, ldb, N, Mb) || bad_ld(layout, ldh, T, N) || bad_ld(layout, ldy, T, Mb))
+        return ST_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipError_t e;
+    if (layout == EVC_FRAME_MAJOR) {
+        // Y[t][mb] = sum_n H[t][n] B[n][mb]           (np.matmul(H.T, B), 04_align_n_nmf.py:391)
+        if (dtype == EVC_F64)
+            e = gemm_strided<double>((const double*)H, ldh, 1, (const double*)B, 1, ldb, (double*)Y, ldy, 1, T, Mb, N, s);
+        else
+            e = gemm_strided<float>((const float*)H, ldh, 1, (const float*)B, 1, ldb, (float*)Y, ldy, 1, T, Mb, N, s);
+    } else {
+        // Y[mb][t] = sum_n B[mb][n] H[n][t]
+        if (dtype == EVC_F64)
+            e = gemm_strided<double>((const double*)B, ldb, 1, (const double*)H, 1, ldh, (double*)Y, ldy, 1, Mb, T, N, s);
+        else
+            e = gemm_strided<float>((const float*)B, ldb, 1, (const float*)H, 1, ldh, (float*)Y, ldy, 1, Mb, T, N, s);
+    }
+    return (int)e;
+}
+
+int evc_residual(const void* A, int lda, const void* X, int ldx, const void* H, int ldh, int M,
+                 int N, int T, int layout, int dtype, double* err2_out, void* workspace,
+                 size_t workspace_bytes, evc_stream_t stream) {
+    if (M < 1 || N < 1 || T < 0) return ST_BADARG;
+    if (layout != EVC_FRAME_MAJOR && layout != EVC_BIN_MAJOR) return ST_BADARG;
+    if (dtype != EVC_F64 && dtype != EVC_F32) return ST_BADARG;
+    if (T == 0) return ST_OK;
+    if (!A || !X || !H || !err2_out || !workspace) return ST_BADARG;
+    if (bad_ld(layout, lda, N, M) || bad_ld(layout, ldx, T, M) || bad_ld(layout, ldh, T, N))
+        return ST_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const Dims d = make_dims(M, N, T, 1);
+    const bool fm = (layout == EVC_FRAME_MAJOR);
+#define EVC_RESID(TT)                                                                              \
+    {                                                                                              \
+        Workspace<TT> w = carve<TT>(workspace, d, EVC_ALGO_FACTORED, MAX_SLOTS, false);             \
+        if (w.bytes > workspace_bytes) return ST_WORKSPACE;                                        \
+        HIP_TRY(copy2d<TT>((const TT*)A, lda, M, N, fm ? 1 : 0, w.Am, d.Np, d.Mj, d.Np, 0, s));     \
+        HIP_TRY(copy2d<TT>((const TT*)X, ldx, T, M, fm ? 0 : 1, w.Xt, d.Mk, d.Tp, d.Mk, 0, s));     \
+        HIP_TRY(copy2d<TT>((const TT*)H, ldh, T, N, fm ? 0 : 1, w.H0, d.Np, d.Tp, d.Np, 0, s));     \
+        HIP_TRY(gemm_nt<TT>(w.H0, d.Np, w.Am, d.Np, w.Vt, d.Mj, d.Tp, d.Mj, d.Np, s));              \
+        HIP_TRY(frame_err2<TT>(w.Xt, d.Mk, w.Vt, d.Mj, M, T, err2_out, s));                         \
+    }
+    if (dtype == EVC_F64) EVC_RESID(double) else EVC_RESID(float)
+#undef EVC_RESID
+    return ST_OK;
+}
+
+}  // extern "C"

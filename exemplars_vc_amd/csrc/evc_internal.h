@@ -1,0 +1,131 @@
+// Internal declarations shared by the translation units of libevc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/evc.h"
+
+namespace evc {
+
+// ------------------------------------------------------------------------------------------
+// MFMA 16x16x4 wrappers.  One operand element per lane for A and B:
+//   A-operand lane l holds Aop[i = l & 15][k = l >> 4]
+//   B-operand lane l holds Bop[k = l >> 4][j = l & 15]
+// C/D (4 values per lane, register r):  column j = l & 15 and
+//   f64: row i = (l >> 4) + 4 r          (v_mfma_f64_16x16x4_f64)
+//   f32: row i = 4 (l >> 4) + r          (v_mfma_f32_16x16x4_f32)
+// ------------------------------------------------------------------------------------------
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Mma;
+template <> struct Mma<double> {
+    typedef f64x4 acc_t;
+    static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
+        return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <> struct Mma<float> {
+    typedef f32x4 acc_t;
+    static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ int row(int lane, int r) { return 4 * (lane >> 4) + r; }
+};
+
+// ------------------------------------------------------------------------------------------
+// The element-wise multiplicative update, one statement per reference surface.
+//   h: current activation, p: numerator (A^T X), d: denominator (A^T A H)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T mu_update(T h, T p, T d, int eps_mode, T eps, T l1) {
+    d += l1;                                        // sklearn _nmf.py:615-617 (l1 == 0: identity)
+    switch (eps_mode) {
+        case EVC_EPS_ADD:                           // pymf nmf.py:68-70
+            return (h * p) / (d + eps);
+        case EVC_EPS_ZERO_REPLACE:                  // sklearn _nmf.py:620-629
+            d = (d == T(0)) ? eps : d;
+            return h * (p / d);
+        case EVC_EPS_CLAMP:                         // deComP batch_mu.py
+            return h * (p / (d > eps ? d : eps));
+        default:                                    // EVC_EPS_NONE, nmf_tool nmf.py:39
+            return (h * p) / d;
+    }
+}
+
+// per-utterance bookkeeping that lives in the workspace
+struct UttState {
+    int* frame_utt;      // [Tp]  utterance index of each frame (padding frames: -1)
+    int* offsets;        // [n_utt+1]
+    int* active;         // [n_utt]
+    int* n_iter;         // [n_utt]
+    double* err_init;    // [n_utt]
+    double* err_prev;    // [n_utt]
+    double* h0;          // [n_utt]   initial activation value (INIT_SKLEARN / CONST)
+    double* trace;       // [n_utt][n_slots]
+    int n_slots;
+};
+
+template <typename T> struct MuEpilogue {
+    const T* Hin;        // [Tp][ldh]
+    const T* P;          // [Tp][ldh]
+    const int* frame_utt;
+    const int* active;
+    int ldh;
+    int N, T_;           // true (unpadded) sizes
+    int eps_mode;
+    T eps, l1;
+};
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// ----- evc_gemm.hip -----
+// C[I x J] = L[I x Kd] * R[J x Kd]^T, all row-major, I % 128 == 0, J % 64 == 0, Kd % 16 == 0.
+template <typename T>
+hipError_t gemm_nt(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int I, int J, int Kd,
+                   hipStream_t s);
+// Same contraction with the multiplicative update as epilogue: C = mu(Hin, P, L R^T).
+template <typename T>
+hipError_t gemm_nt_mu(const T* L, int ldl, const T* R, int ldr, T* Hout, int I, int J, int Kd,
+                      const MuEpilogue<T>& ep, hipStream_t s);
+// Bounds-checked general-stride contraction on caller memory (used by evc_synthesize):
+// C[i*csi + j*csj] = sum_k L[i*lsi + k*lsk] * R[j*rsj + k*rsk]
+template <typename T>
+hipError_t gemm_strided(const T* L, long lsi, long lsk, const T* R, long rsj, long rsk, T* C,
+                        long csi, long csj, int I, int J, int Kd, hipStream_t s);
+
+// ----- evc_aux.hip -----
+// dst (dst_rows x dst_cols, row stride dst_ld) = src (src_rows x src_cols), zero outside src.
+// src_trans: element (r,c) of the logical matrix is src[c*src_ld + r] instead of src[r*src_ld + c];
+// dst_trans likewise for the destination.
+template <typename T>
+hipError_t copy2d(const T* src, long src_ld, int src_rows, int src_cols, int src_trans, T* dst,
+                  long dst_ld, int dst_rows, int dst_cols, int dst_trans, hipStream_t s);
+hipError_t utt_single(const UttState& u, int T_, hipStream_t s);
+hipError_t utt_setup(const UttState& u, int n_utt, int T_, int Tp, int iters, hipStream_t s);
+template <typename T>
+hipError_t utt_sklearn_h0(const T* Xt, int ldx, int M, int N, const UttState& u, int n_utt,
+                          hipStream_t s);
+hipError_t utt_const_h0(const UttState& u, int n_utt, double v, hipStream_t s);
+template <typename T>
+hipError_t fill_h0(T* Ht, int ldh, int Tp, int N, int T_, const UttState& u, hipStream_t s);
+template <typename T>
+hipError_t frame_err2(const T* Xt, int ldx, const T* Vt, int ldv, int M, int T_, double* err2,
+                      hipStream_t s);
+// evaluate the stopping rule after check number `c` (c == 0: error at init)
+hipError_t utt_check(const double* err2, const UttState& u, int n_utt, int c, int check_every,
+                     int stop_rule, double tol, hipStream_t s);
+
+// ----- evc_fused.hip -----
+// Persistent fused FACTORED kernel for small dictionaries heights (M <= 32), float64.
+struct FusedPlan {
+    int M, N, T_;        // true sizes
+    int NT;              // N tiles of 16
+    int TT;              // frame tiles of 16
+    int msteps;          // k-steps of 4 bins actually issued
+    int mtiles;          // 1 (M <= 16) or 2
+};
+bool fused_supported(int M, int N, int T_, int dtype);
+size_t fused_workspace_bytes(int M, int N, int T_);
+
+}  // namespace evc

@@ -1,0 +1,248 @@
+"""Host-side plumbing for the HIP activation solver: device buffers, streams, workspace.
+
+PyTorch is used for device memory and stream handles only; all arithmetic happens in
+libevc_hip.so (hand-written gfx950 kernels) behind the C ABI of include/evc.h.
+
+Orientation (`layout`):
+  "bin_major"   - north_star / pymf / nmf_tool: A (M,N), X (M,T), H (N,T), B (Mb,N), Y (Mb,T)
+  "frame_major" - the reference scripts (04_align_n_nmf.py): A (N,M), X (T,M), H (T,N),
+                  B (N,Mb), Y (T,Mb)
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+
+_EPS_MODES = {"add": _lib.EPS_ADD, "zero_replace": _lib.EPS_ZERO_REPLACE, "none": _lib.EPS_NONE,
+              "clamp": _lib.EPS_CLAMP}
+_EPS_DEFAULT = {"add": 1e-9, "zero_replace": float(np.finfo(np.float32).eps), "none": 0.0,
+                "clamp": 1e-15}
+_ALGOS = {"gram": _lib.ALGO_GRAM, "factored": _lib.ALGO_FACTORED, "literal": _lib.ALGO_LITERAL,
+          "auto": _lib.ALGO_AUTO}
+_INITS = {"given": _lib.INIT_GIVEN, "sklearn": _lib.INIT_SKLEARN, "const": _lib.INIT_CONST}
+_STOPS = {"none": _lib.STOP_NONE, "sklearn": _lib.STOP_SKLEARN, "pymf": _lib.STOP_PYMF}
+_LAYOUTS = {"frame_major": _lib.FRAME_MAJOR, "bin_major": _lib.BIN_MAJOR}
+
+_workspaces = {}
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def require_device(device=None):
+    """Resolve the HIP device to run on; raise if there is none (no CPU fallback)."""
+    torch = _torch()
+    _lib.lib()  # fail early and loudly when the native library is missing
+    if not torch.cuda.is_available():
+        raise RuntimeError("exemplars_vc_amd needs a HIP device (torch.cuda.is_available() is False); "
+                           "there is no CPU fallback")
+    if device is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError(f"exemplars_vc_amd runs on HIP devices only, got {device}")
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
+def _workspace(nbytes: int, device):
+    torch = _torch()
+    key = (device.index,)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        _workspaces.pop(key, None)
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def release_workspaces():
+    _workspaces.clear()
+
+
+def _to_dev(x, tdtype, device):
+    """2-D array/tensor -> device tensor with unit inner stride; returns (tensor, was_numpy)."""
+    torch = _torch()
+    was_numpy = not isinstance(x, torch.Tensor)
+    if was_numpy:
+        x = torch.from_numpy(np.ascontiguousarray(np.asarray(x)))
+    if x.dim() != 2:
+        raise ValueError(f"expected a 2-D matrix, got shape {tuple(x.shape)}")
+    x = x.to(device=device, dtype=tdtype)
+    if x.shape[1] > 1 and x.stride(1) != 1 or (x.shape[0] > 1 and x.stride(0) < x.shape[1]):
+        x = x.contiguous()
+    return x, was_numpy
+
+
+def _ld(x):
+    return int(x.stride(0)) if x.shape[0] > 1 else int(max(x.shape[1], 1))
+
+
+def _pick_dtype(dtype, *arrs):
+    torch = _torch()
+    if dtype is None:
+        for a in arrs:
+            if a is None:
+                continue
+            dt = a.dtype
+            if dt in (np.float32, torch.float32):
+                return torch.float32, _lib.F32
+            break
+        return torch.float64, _lib.F64
+    if dtype in ("f32", "float32", np.float32, torch.float32):
+        return torch.float32, _lib.F32
+    if dtype in ("f64", "float64", np.float64, torch.float64, float):
+        return torch.float64, _lib.F64
+    raise ValueError(f"unsupported dtype {dtype!r}")
+
+
+def workspace_bytes(M, N, T, n_utt=1, dtype="f64", algo="auto"):
+    _, code = _pick_dtype(dtype)
+    return int(_lib.lib().evc_workspace_bytes(M, N, T, n_utt, code, _ALGOS[algo]))
+
+
+def solve_activations(A, X, H0=None, *, layout="bin_major", iters=100, eps_mode="add", eps=None,
+                      l1=0.0, algo="auto", init=None, init_value=0.0, check_every=0,
+                      stop_rule="none", tol=0.0, utt_offsets: Optional[Sequence[int]] = None,
+                      dtype=None, device=None, info=False, out=None):
+    """H <- H (.) A^T X (/) guard(A^T A H + l1), `iters` times, on the GPU.
+
+    Returns H in the caller's orientation (numpy in -> numpy out, device tensor in -> device
+    tensor out); with info=True also a dict(n_iter=int array per utterance, err=array
+    [n_utt, 1+iters//check_every] of residuals, NaN where not evaluated).
+    """
+    torch = _torch()
+    device = require_device(device)
+    L = _lib.lib()
+    lay = _LAYOUTS[layout]
+    tdtype, dcode = _pick_dtype(dtype, X, A)
+    A_d, _ = _to_dev(A, tdtype, device)
+    X_d, x_np = _to_dev(X, tdtype, device)
+    if lay == _lib.BIN_MAJOR:
+        M, N = A_d.shape
+        M2, T = X_d.shape
+        hshape = (N, T)
+    else:
+        N, M = A_d.shape
+        T, M2 = X_d.shape
+        hshape = (T, N)
+    if M2 != M:
+        raise ValueError(f"A and X disagree on the number of bins: {M} vs {M2}")
+    if init is None:
+        init = "given" if H0 is not None else "sklearn"
+    if init == "given":
+        if H0 is None:
+            raise ValueError("init='given' needs H0")
+        H_d, _ = _to_dev(H0, tdtype, device)
+        if tuple(H_d.shape) != hshape:
+            raise ValueError(f"H0 has shape {tuple(H_d.shape)}, expected {hshape}")
+        if out is not None:
+            out.copy_(H_d)
+            H_d = out
+        elif isinstance(H0, torch.Tensor) and H_d.data_ptr() == H0.data_ptr():
+            H_d = H_d.clone()       # never clobber the caller's H0
+    else:
+        H_d = out if out is not None else torch.empty(hshape, dtype=tdtype, device=device)
+    if tuple(H_d.shape) != hshape or H_d.dtype != tdtype or (H_d.shape[1] > 1 and H_d.stride(1) != 1):
+        raise ValueError("`out` must be a contiguous device tensor of the activation shape/dtype")
+
+    if utt_offsets is None:
+        n_utt, off_arr, off_ptr = 1, None, None
+    else:
+        off_arr = np.ascontiguousarray(np.asarray(utt_offsets, dtype=np.int32))
+        n_utt = len(off_arr) - 1
+        if n_utt < 1:
+            raise ValueError("utt_offsets needs at least two entries")
+        off_ptr = off_arr.ctypes.data_as(C.POINTER(C.c_int))
+
+    opts = _lib.SolveOpts()
+    opts.struct_bytes = C.sizeof(_lib.SolveOpts)
+    opts.dtype, opts.layout, opts.algo = dcode, lay, _ALGOS[algo]
+    opts.iters, opts.eps_mode, opts.init_mode = int(iters), _EPS_MODES[eps_mode], _INITS[init]
+    opts.check_every, opts.stop_rule = int(check_every), _STOPS[stop_rule]
+    opts.eps = _EPS_DEFAULT[eps_mode] if eps is None else float(eps)
+    opts.l1, opts.tol, opts.init_value = float(l1), float(tol), float(init_value)
+
+    ws_bytes = int(L.evc_workspace_bytes(M, N, T, n_utt, dcode, opts.algo))
+    ws = _workspace(ws_bytes, device)
+    n_slots = 1 + (iters // check_every if check_every > 0 else 0)
+    n_iter = np.zeros(n_utt, dtype=np.int32) if info else None
+    err = np.full((n_utt, n_slots), np.nan) if info else None
+    with torch.cuda.device(device):
+        stream = torch.cuda.current_stream(device).cuda_stream
+        st = L.evc_nmf_solve(
+            A_d.data_ptr(), _ld(A_d), X_d.data_ptr(), _ld(X_d), H_d.data_ptr(), _ld(H_d),
+            M, N, T, off_ptr, n_utt, C.byref(opts), ws.data_ptr(), ws.numel(),
+            n_iter.ctypes.data_as(C.POINTER(C.c_int)) if info else None,
+            err.ctypes.data_as(C.POINTER(C.c_double)) if info else None,
+            C.c_void_p(stream))
+    _lib.check(st, "evc_nmf_solve")
+    H_out = H_d.cpu().numpy() if x_np and out is None else H_d
+    if info:
+        return H_out, {"n_iter": n_iter, "err": err}
+    return H_out
+
+
+def synthesize(B, H, *, layout="bin_major", dtype=None, device=None):
+    """Y = B H (bin_major, (Mb,T)) or H B (frame_major: np.matmul(H.T, B) of
+    04_align_n_nmf.py:391 with H already frames-as-rows, giving (T,Mb))."""
+    torch = _torch()
+    device = require_device(device)
+    L = _lib.lib()
+    lay = _LAYOUTS[layout]
+    tdtype, dcode = _pick_dtype(dtype, H, B)
+    B_d, _ = _to_dev(B, tdtype, device)
+    H_d, h_np = _to_dev(H, tdtype, device)
+    if lay == _lib.BIN_MAJOR:
+        Mb, N = B_d.shape
+        N2, T = H_d.shape
+        yshape = (Mb, T)
+    else:
+        N, Mb = B_d.shape
+        T, N2 = H_d.shape
+        yshape = (T, Mb)
+    if N2 != N:
+        raise ValueError(f"B and H disagree on the number of exemplars: {N} vs {N2}")
+    Y = torch.empty(yshape, dtype=tdtype, device=device)
+    with torch.cuda.device(device):
+        stream = torch.cuda.current_stream(device).cuda_stream
+        st = L.evc_synthesize(B_d.data_ptr(), _ld(B_d), H_d.data_ptr(), _ld(H_d), Y.data_ptr(),
+                              _ld(Y), Mb, N, T, lay, dcode, C.c_void_p(stream))
+    _lib.check(st, "evc_synthesize")
+    return Y.cpu().numpy() if h_np else Y
+
+
+def frame_residuals(A, X, H, *, layout="bin_major", dtype=None, device=None):
+    """Per-frame squared residual sum_m (X - A H)^2 (float64, length T)."""
+    torch = _torch()
+    device = require_device(device)
+    L = _lib.lib()
+    lay = _LAYOUTS[layout]
+    tdtype, dcode = _pick_dtype(dtype, X, A)
+    A_d, _ = _to_dev(A, tdtype, device)
+    X_d, x_np = _to_dev(X, tdtype, device)
+    H_d, _ = _to_dev(H, tdtype, device)
+    if lay == _lib.BIN_MAJOR:
+        M, N = A_d.shape
+        T = X_d.shape[1]
+    else:
+        N, M = A_d.shape
+        T = X_d.shape[0]
+    err2 = torch.zeros(max(T, 1), dtype=torch.float64, device=device)
+    ws_bytes = int(L.evc_workspace_bytes(M, N, T, 1, dcode, _lib.ALGO_FACTORED))
+    ws = _workspace(ws_bytes, device)
+    with torch.cuda.device(device):
+        stream = torch.cuda.current_stream(device).cuda_stream
+        st = L.evc_residual(A_d.data_ptr(), _ld(A_d), X_d.data_ptr(), _ld(X_d), H_d.data_ptr(),
+                            _ld(H_d), M, N, T, lay, dcode, err2.data_ptr(), ws.data_ptr(),
+                            ws.numel(), C.c_void_p(stream))
+    _lib.check(st, "evc_residual")
+    err2 = err2[:T]
+    return err2.cpu().numpy() if x_np else err2

@@ -1,0 +1,145 @@
+/*
+ * evc.h - C ABI of libevc_hip.so: the MI355X (gfx950) exemplar-NMF activation solver.
+ *
+ * The reference (entn-at/exemplars_vc) is pure Python and has no FFI of its own; the
+ * boundary of its hot path is three plain-Python call surfaces.  This header is the
+ * native boundary those surfaces bind to (see INTEGRATION.md for the ctypes stubs):
+ *
+ *   evc_nmf_solve   replaces the multiplicative-update loop behind
+ *                     - _factorize()                    04_align_n_nmf.py:194-215
+ *                       (sklearn _fit_multiplicative_update, _nmf.py:731-893,
+ *                        _multiplicative_update_w beta=2 branch, _nmf.py:526-556,612-631)
+ *                     - pymf NMF._update_h / factorize  pymf/nmf.py:66-70, pymf/base.py:208-270
+ *                     - nmf_tool NMF.NMF (mu, initW)    nmf_tool/nmf.py:36-40,57-67
+ *   evc_synthesize  replaces np.matmul(H.T, B) in convert()  04_align_n_nmf.py:371-373,391
+ *   evc_residual    replaces sklearn _beta_divergence(beta=2, square_root=True)
+ *                   (_nmf.py:85-135) and pymf frobenius_norm (pymf/base.py:144-165)
+ *
+ * Conventions
+ *   Math (BASELINE.json north_star): X is M x T (bins x frames), A is M x N (source
+ *   exemplar dictionary), B is Mb x N (parallel target dictionary), H is N x T, Y = B H.
+ *   All pointers are DEVICE pointers unless marked "host".  Nothing here allocates,
+ *   frees or throws; every function returns a status (0 ok, <0 invalid argument,
+ *   >0 a hipError_t value).  Work is enqueued on `stream`; the only host synchronisation
+ *   is the one needed to hand back n_iter/err when those host pointers are non-NULL.
+ *   No global mutable state: calls on distinct streams/devices are independent and the
+ *   caller's current device (hipSetDevice) is honoured.
+ */
+#ifndef EVC_H
+#define EVC_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EVC_VERSION 100 /* 0.1.0 */
+
+/* hipStream_t, spelled without the HIP headers so that C callers can include this file. */
+typedef struct ihipStream_t* evc_stream_t;
+
+/* element type of every matrix in a call (the arithmetic is carried out in the same type) */
+enum { EVC_F64 = 0, EVC_F32 = 1 };
+
+/* storage order of the caller's matrices
+ *   FRAME_MAJOR : the reference scripts' orientation (frames / exemplars as rows):
+ *                 X[t*ldx+m]  A[n*lda+m]  B[n*ldb+mb]  H[t*ldh+n]  Y[t*ldy+mb]
+ *                 (X = `X` T x M, A = `W` N x M of _factorize; H = sklearn's W, T x N)
+ *   BIN_MAJOR   : the north_star / pymf / nmf_tool orientation (bins as rows):
+ *                 X[m*ldx+t]  A[m*lda+n]  B[mb*ldb+n] H[n*ldh+t]  Y[mb*ldy+t]          */
+enum { EVC_FRAME_MAJOR = 0, EVC_BIN_MAJOR = 1 };
+
+/* how the denominator D = A^T A H (+ l1) is guarded, and the multiply/divide order
+ *   ADD          H <- (H*P) / (D + eps)            pymf nmf.py:68-70      (eps = 1e-9)
+ *   ZERO_REPLACE D[D==0] = eps; H <- H * (P/D)     sklearn _nmf.py:620-629 (eps = 1.1920929e-7)
+ *   NONE         H <- H * P / D                    nmf_tool nmf.py:39
+ *   CLAMP        H <- H * (P / max(D, eps))        deComP batch_mu.py:8-26 (eps = 1e-15)   */
+enum { EVC_EPS_ADD = 0, EVC_EPS_ZERO_REPLACE = 1, EVC_EPS_NONE = 2, EVC_EPS_CLAMP = 3 };
+
+/* which algebra evaluates the denominator
+ *   GRAM      G = A^T A and P = A^T X once, then G H per iteration (sklearn's hoisting)
+ *   FACTORED  A^T (A H) per iteration: 4MN instead of 2N^2 flop per frame-iteration
+ *   LITERAL   G and P recomputed in every iteration, as pymf/nmf_tool literally do
+ *   AUTO      FACTORED                                                                    */
+enum { EVC_ALGO_GRAM = 0, EVC_ALGO_FACTORED = 1, EVC_ALGO_LITERAL = 2, EVC_ALGO_AUTO = 3 };
+
+/* initial activations
+ *   GIVEN    H holds H0 on entry (pymf / nmf_tool: random, caller-seeded)
+ *   SKLEARN  every entry of utterance u starts at sqrt(mean(X_u) / N)  (_nmf.py:1228-1231)
+ *   CONST    every entry starts at init_value                                              */
+enum { EVC_INIT_GIVEN = 0, EVC_INIT_SKLEARN = 1, EVC_INIT_CONST = 2 };
+
+/* stopping rule, evaluated per utterance every `check_every` iterations on
+ * err = ||X_u - A H_u||_F
+ *   NONE     errors are recorded (if check_every > 0) but never stop the loop
+ *   SKLEARN  stop when (err_prev - err) / err_at_init < tol       (_nmf.py:871-884)
+ *   PYMF     from the third recorded error on, stop when |err - err_prev| / T_u < tol
+ *            (pymf/base.py:189-206,266-270)                                               */
+enum { EVC_STOP_NONE = 0, EVC_STOP_SKLEARN = 1, EVC_STOP_PYMF = 2 };
+
+typedef struct evc_solve_opts {
+    int struct_bytes;  /* sizeof(evc_solve_opts), for forward compatibility */
+    int dtype;         /* EVC_F64 | EVC_F32 */
+    int layout;        /* EVC_FRAME_MAJOR | EVC_BIN_MAJOR */
+    int algo;          /* EVC_ALGO_* */
+    int iters;         /* maximum number of multiplicative updates (>= 0) */
+    int eps_mode;      /* EVC_EPS_* */
+    int init_mode;     /* EVC_INIT_* */
+    int check_every;   /* 0: never evaluate the residual; k>0: every k iterations */
+    int stop_rule;     /* EVC_STOP_* */
+    int reserved;
+    double eps;        /* guard value for eps_mode */
+    double l1;         /* added to the denominator (sklearn l1_reg_W = M*alpha_W*l1_ratio) */
+    double tol;        /* threshold of stop_rule */
+    double init_value; /* EVC_INIT_CONST */
+} evc_solve_opts;
+
+int evc_version(void);
+const char* evc_strerror(int status);
+
+/* number of GPUs visible to the library (hipGetDeviceCount); <0 on failure */
+int evc_device_count(void);
+
+/* Bytes of device workspace evc_nmf_solve needs for a problem of this size.
+ * n_utt is the number of utterances the T frames are split into (>= 1). */
+size_t evc_workspace_bytes(int M, int N, int T, int n_utt, int dtype, int algo);
+
+/* Solve X ~ A H for H >= 0 with A fixed: `iters` multiplicative updates
+ *   H <- H (.) A^T X (/) guard(A^T A H + l1).
+ *
+ * The T frames are the concatenation of n_utt utterances; utt_offsets (host, n_utt+1
+ * ascending ints, utt_offsets[0]=0, utt_offsets[n_utt]=T) delimits them, NULL means one
+ * utterance.  Utterances only matter for EVC_INIT_SKLEARN and for the stopping rule, both
+ * of which the reference applies per call, i.e. per utterance: frames of a stopped
+ * utterance are frozen while the others go on.
+ *
+ * n_iter_out (host, n_utt ints or NULL): updates applied to each utterance.
+ * err_out    (host, n_utt * (1 + iters/check_every) doubles or NULL): per utterance, the
+ *            residual at init followed by the residual at each check that was evaluated
+ *            (unevaluated slots are NaN).
+ * When both are NULL the call is fully asynchronous.                                    */
+int evc_nmf_solve(const void* A, int lda, const void* X, int ldx, void* H, int ldh,
+                  int M, int N, int T,
+                  const int* utt_offsets, int n_utt,
+                  const evc_solve_opts* opts,
+                  void* workspace, size_t workspace_bytes,
+                  int* n_iter_out, double* err_out,
+                  evc_stream_t stream);
+
+/* Y = B H  (04_align_n_nmf.py:391: np.matmul(H.T, B) in FRAME_MAJOR orientation). */
+int evc_synthesize(const void* B, int ldb, const void* H, int ldh, void* Y, int ldy,
+                   int Mb, int N, int T, int layout, int dtype, evc_stream_t stream);
+
+/* err2_out[t] (device, T values of `dtype`... always double) = sum_m (X[m,t] - (A H)[m,t])^2.
+ * The Frobenius residual of a set of frames is sqrt of the sum of its entries.
+ * workspace: evc_workspace_bytes(M, N, T, 1, dtype, EVC_ALGO_FACTORED) suffices.       */
+int evc_residual(const void* A, int lda, const void* X, int ldx, const void* H, int ldh,
+                 int M, int N, int T, int layout, int dtype,
+                 double* err2_out, void* workspace, size_t workspace_bytes,
+                 evc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EVC_H */
