@@ -30,6 +30,7 @@ class SolveOpts(C.Structure):
         ("iters", C.c_int), ("eps_mode", C.c_int), ("init_mode", C.c_int),
         ("check_every", C.c_int), ("stop_rule", C.c_int), ("reserved", C.c_int),
         ("eps", C.c_double), ("l1", C.c_double), ("tol", C.c_double), ("init_value", C.c_double),
+        ("ev_loop_start", C.c_void_p), ("ev_loop_stop", C.c_void_p),
     ]
 
 

@@ -41,23 +41,36 @@ template <typename T> struct Workspace {
     T *At, *Am, *Xt, *H0, *H1, *Pt, *G, *Vt;
     double* err2;
     UttState u;
-    void* fused;
+    FusedLayout fl;
+    FusedBuffers fb;
+    bool fused;
     size_t bytes;
 };
 
 int n_slots_for(int iters, int check_every) { return 1 + (check_every > 0 ? iters / check_every : 0); }
 
 template <typename T>
-Workspace<T> carve(void* base, const Dims& d, int algo, int n_slots, bool with_fused) {
+Workspace<T> carve(void* base, const Dims& d, int algo, int n_slots, bool fused) {
     Workspace<T> w;
     Carver c{static_cast<char*>(base), 0};
     const bool gram = (algo == EVC_ALGO_GRAM || algo == EVC_ALGO_LITERAL);
+    w.fused = fused;
     w.At = c.take<T>((size_t)d.Np * d.Mk);
     w.Am = c.take<T>((size_t)d.Mj * d.Np);
     w.Xt = c.take<T>((size_t)d.Tp * d.Mk);
     w.H0 = c.take<T>((size_t)d.Tp * d.Np);
-    w.Pt = c.take<T>((size_t)d.Tp * d.Np);
-    w.Vt = c.take<T>((size_t)d.Tp * d.Mj);
+    w.Pt = fused ? nullptr : c.take<T>((size_t)d.Tp * d.Np);
+    w.Vt = fused ? nullptr : c.take<T>((size_t)d.Tp * d.Mj);
+    w.fl = FusedLayout{};
+    w.fb = FusedBuffers{};
+    if (fused) {
+        w.fl = fused_layout(d.M, d.N, d.T_);
+        w.fb.A1p = c.take<double>(w.fl.a1);
+        w.fb.A2p = c.take<double>(w.fl.a2);
+        w.fb.Xp = c.take<double>(w.fl.xp);
+        w.fb.Hp = c.take<double>(w.fl.hp);
+        w.fb.Vp = c.take<double>(w.fl.vp);
+    }
     w.H1 = gram ? c.take<T>((size_t)d.Tp * d.Np) : nullptr;
     w.G = gram ? c.take<T>((size_t)d.Np * d.Np) : nullptr;
     w.err2 = c.take<double>(d.Tp);
@@ -70,10 +83,12 @@ Workspace<T> carve(void* base, const Dims& d, int algo, int n_slots, bool with_f
     w.u.h0 = c.take<double>(d.n_utt);
     w.u.trace = c.take<double>((size_t)d.n_utt * n_slots);
     w.u.n_slots = n_slots;
-    w.fused = nullptr;
-    (void)with_fused;
     w.bytes = (c.off + 255) & ~size_t(255);
     return w;
+}
+
+bool use_fused(int M, int N, int T_, int dtype, int algo) {
+    return algo == EVC_ALGO_FACTORED && fused_supported(M, N, T_, dtype);
 }
 
 #define HIP_TRY(expr)                              \
@@ -86,6 +101,60 @@ Workspace<T> carve(void* base, const Dims& d, int algo, int n_slots, bool with_f
 // so the trace region is sized for MAX_SLOTS checks and evc_nmf_solve rejects more.
 constexpr int MAX_SLOTS = 4097;
 
+// export the activations to the caller's layout and hand back the per-utterance results
+template <typename T>
+int finish(const Workspace<T>& w, const Dims& d, const evc_solve_opts& o, const T* Hc, T* H, int ldh,
+           int n_utt, int n_slots, int* n_iter_out, double* err_out, hipStream_t s) {
+    const bool fm = (o.layout == EVC_FRAME_MAJOR);
+    HIP_TRY(copy2d<T>(Hc, d.Np, d.T_, d.N, 0, H, ldh, d.T_, d.N, fm ? 0 : 1, s));
+    if (n_iter_out || err_out) {
+        if (n_iter_out)
+            HIP_TRY(hipMemcpyAsync(n_iter_out, w.u.n_iter, sizeof(int) * n_utt, hipMemcpyDeviceToHost, s));
+        if (err_out)
+            HIP_TRY(hipMemcpyAsync(err_out, w.u.trace, sizeof(double) * (size_t)n_utt * n_slots,
+                                   hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return ST_OK;
+}
+
+// The fused persistent path (float64, M <= 32): one launch per `check_every` iterations (or a
+// single launch when no residual is requested); V is carried between launches.
+template <typename T>
+int solve_fused(const Workspace<T>& w, const Dims& d, const evc_solve_opts& o, int n_utt, hipStream_t s) {
+    return ST_UNSUPPORTED;
+}
+template <>
+int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_solve_opts& o, int n_utt,
+                        hipStream_t s) {
+    const int c_override = (o.reserved >> 8) & 0xff;
+    HIP_TRY(fused_pack(w.fl, w.fb, w.At, d.Mk, w.Xt, d.Mk, w.H0, d.Np, s));
+    int first = 1;
+    if (o.check_every > 0 && o.stop_rule == EVC_STOP_SKLEARN) {   // error_at_init
+        HIP_TRY(fused_iterate(w.fl, w.fb, w.u, d.N, d.T_, 0, 1, 1, w.err2, o.eps_mode, o.eps, o.l1,
+                              c_override, s));
+        HIP_TRY(utt_check(w.err2, w.u, n_utt, 0, o.check_every, o.stop_rule, o.tol, s));
+        first = 0;
+    }
+    if (o.ev_loop_start) HIP_TRY(hipEventRecord((hipEvent_t)o.ev_loop_start, s));
+    int done = 0;
+    while (done < o.iters) {
+        int n = o.iters - done;
+        bool check = false;
+        if (o.check_every > 0 && n >= o.check_every) { n = o.check_every; check = true; }
+        HIP_TRY(fused_iterate(w.fl, w.fb, w.u, d.N, d.T_, n, first, check ? 1 : 0, w.err2, o.eps_mode,
+                              o.eps, o.l1, c_override, s));
+        first = 0;
+        done += n;
+        if (check)
+            HIP_TRY(utt_check(w.err2, w.u, n_utt, done / o.check_every, o.check_every, o.stop_rule,
+                              o.tol, s));
+    }
+    if (o.ev_loop_stop) HIP_TRY(hipEventRecord((hipEvent_t)o.ev_loop_stop, s));
+    HIP_TRY(fused_unpack(w.fl, w.fb, w.H0, d.Np, s));
+    return ST_OK;
+}
+
 template <typename T>
 int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int ldh, int M, int N,
                 int T_, const int* utt_offsets, int n_utt, const evc_solve_opts& o, void* ws,
@@ -97,7 +166,8 @@ int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int 
     int algo = o.algo == EVC_ALGO_AUTO ? EVC_ALGO_FACTORED : o.algo;
     const int n_slots = n_slots_for(o.iters, o.check_every);
     if (n_slots > MAX_SLOTS) return ST_UNSUPPORTED;
-    Workspace<T> w = carve<T>(ws, d, algo, MAX_SLOTS, false);
+    const bool fused = use_fused(M, N, T_, o.dtype, algo) && !(o.reserved & 1);
+    Workspace<T> w = carve<T>(ws, d, algo, MAX_SLOTS, fused);
     if (w.bytes > ws_bytes) return ST_WORKSPACE;
     w.u.n_slots = n_slots;
     const bool fm = (o.layout == EVC_FRAME_MAJOR);
@@ -120,6 +190,12 @@ int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int 
         if (o.init_mode == EVC_INIT_SKLEARN) HIP_TRY(utt_sklearn_h0<T>(w.Xt, d.Mk, M, N, w.u, n_utt, s));
         else HIP_TRY(utt_const_h0(w.u, n_utt, o.init_value, s));
         HIP_TRY(fill_h0<T>(w.H0, d.Np, d.Tp, N, T_, w.u, s));
+    }
+
+    if (fused) {
+        int st = solve_fused(w, d, o, n_utt, s);
+        if (st) return st;
+        return finish<T>(w, d, o, w.H0, H, ldh, n_utt, n_slots, n_iter_out, err_out, s);
     }
 
     // ---- numerator (and Gram matrix) ----
@@ -148,6 +224,7 @@ int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int 
     ep.P = w.Pt; ep.frame_utt = w.u.frame_utt; ep.active = w.u.active; ep.ldh = d.Np;
     ep.N = N; ep.T_ = T_; ep.eps_mode = o.eps_mode; ep.eps = (T)o.eps; ep.l1 = (T)o.l1;
 
+    if (o.ev_loop_start) HIP_TRY(hipEventRecord((hipEvent_t)o.ev_loop_start, s));
     for (int it = 1; it <= o.iters; ++it) {
         if (algo == EVC_ALGO_LITERAL) {   // pymf nmf.py:68-69 recomputes both every iteration
             HIP_TRY(gemm_nt<T>(w.At, d.Mk, w.At, d.Mk, w.G, d.Np, d.Np, d.Np, d.Mk, s));
@@ -169,22 +246,18 @@ int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int 
         }
     }
 
-    // ---- export ----
-    HIP_TRY(copy2d<T>(Hc, d.Np, T_, N, 0, H, ldh, T_, N, fm ? 0 : 1, s));
-    if (n_iter_out || err_out) {
-        if (n_iter_out)
-            HIP_TRY(hipMemcpyAsync(n_iter_out, w.u.n_iter, sizeof(int) * n_utt, hipMemcpyDeviceToHost, s));
-        if (err_out)
-            HIP_TRY(hipMemcpyAsync(err_out, w.u.trace, sizeof(double) * (size_t)n_utt * n_slots,
-                                   hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-    }
-    return ST_OK;
+    if (o.ev_loop_stop) HIP_TRY(hipEventRecord((hipEvent_t)o.ev_loop_stop, s));
+    return finish<T>(w, d, o, Hc, H, ldh, n_utt, n_slots, n_iter_out, err_out, s);
 }
 
 template <typename T> size_t workspace_typed(int M, int N, int T_, int n_utt, int algo) {
     const Dims d = make_dims(M, N, T_, n_utt);
-    return carve<T>(nullptr, d, algo == EVC_ALGO_AUTO ? EVC_ALGO_FACTORED : algo, MAX_SLOTS, true).bytes;
+    const int al = algo == EVC_ALGO_AUTO ? EVC_ALGO_FACTORED : algo;
+    const int dt = sizeof(T) == 8 ? EVC_F64 : EVC_F32;
+    // the generic carve is never smaller than the fused one minus the packed arrays; take the max
+    const size_t a = carve<T>(nullptr, d, al, MAX_SLOTS, false).bytes;
+    const size_t b = use_fused(M, N, T_, dt, al) ? carve<T>(nullptr, d, al, MAX_SLOTS, true).bytes : 0;
+    return a > b ? a : b;
 }
 
 bool bad_ld(int layout, int ld, int rows_fm, int cols_fm) {

@@ -118,14 +118,26 @@ hipError_t utt_check(const double* err2, const UttState& u, int n_utt, int c, in
 
 // ----- evc_fused.hip -----
 // Persistent fused FACTORED kernel for small dictionaries heights (M <= 32), float64.
-struct FusedPlan {
-    int M, N, T_;        // true sizes
-    int NT;              // N tiles of 16
-    int TT;              // frame tiles of 16
+struct FusedLayout {
+    int NT;              // exemplar tiles of 16
+    int TT, TTp;         // frame tiles of 16 (TTp: padded to a multiple of 4)
     int msteps;          // k-steps of 4 bins actually issued
     int mtiles;          // 1 (M <= 16) or 2
+    size_t a1, a2, xp, hp, vp;   // element counts of the packed arrays
+};
+struct FusedBuffers {
+    double *A1p, *A2p, *Xp, *Hp, *Vp;
 };
 bool fused_supported(int M, int N, int T_, int dtype);
-size_t fused_workspace_bytes(int M, int N, int T_);
+FusedLayout fused_layout(int M, int N, int T_);
+// At[n][m] / Xt[t][m] / Ht[t][n]: the zero-padded frames-as-rows workspace arrays
+hipError_t fused_pack(const FusedLayout& f, const FusedBuffers& b, const double* At, int ldA,
+                      const double* Xt, int ldx, double* Ht, int ldh, hipStream_t s);
+hipError_t fused_unpack(const FusedLayout& f, const FusedBuffers& b, double* Ht, int ldh, hipStream_t s);
+// `iters` updates in one launch.  first: V is built from H by a pre-pass (else carried over in
+// Vp from the previous launch); write_err: per-frame squared residuals of the final H -> err2.
+hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttState& u, int N, int T_,
+                         int iters, int first, int write_err, double* err2, int eps_mode, double eps,
+                         double l1, int c_override, hipStream_t s);
 
 }  // namespace evc

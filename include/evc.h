@@ -93,6 +93,11 @@ typedef struct evc_solve_opts {
     double l1;         /* added to the denominator (sklearn l1_reg_W = M*alpha_W*l1_ratio) */
     double tol;        /* threshold of stop_rule */
     double init_value; /* EVC_INIT_CONST */
+    /* optional hipEvent_t pair recorded on `stream` immediately before / after the launches of
+     * the iteration loop (the dominant kernel); NULL = not recorded.  Used by bench.py to time
+     * that kernel live with HIP events. */
+    void* ev_loop_start;
+    void* ev_loop_stop;
 } evc_solve_opts;
 
 int evc_version(void);
