@@ -325,9 +325,8 @@ static hipError_t dispatch_msteps(int msteps, const FusedArgs& a, hipStream_t s)
 
 int fused_pick_c(int T_) {
     const int TT = (T_ + 15) / 16;
-    if (TT >= 4096) return 4;     // >= 1024 workgroups of 64 frames
-    if (TT >= 1024) return 2;
-    return 1;
+    if (TT >= 1024) return 2;     // >= 512 workgroups of 32 frames: amortise the dictionary reads
+    return 1;                     // few frames: as many workgroups as possible
 }
 
 hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttState& u, int N, int T_,

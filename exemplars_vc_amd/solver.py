@@ -111,7 +111,8 @@ def workspace_bytes(M, N, T, n_utt=1, dtype="f64", algo="auto"):
 def solve_activations(A, X, H0=None, *, layout="bin_major", iters=100, eps_mode="add", eps=None,
                       l1=0.0, algo="auto", init=None, init_value=0.0, check_every=0,
                       stop_rule="none", tol=0.0, utt_offsets: Optional[Sequence[int]] = None,
-                      dtype=None, device=None, info=False, out=None, loop_events=None):
+                      dtype=None, device=None, info=False, out=None, loop_events=None,
+                      fused=True, fused_c=0):
     """H <- H (.) A^T X (/) guard(A^T A H + l1), `iters` times, on the GPU.
 
     Returns H in the caller's orientation (numpy in -> numpy out, device tensor in -> device
@@ -169,6 +170,9 @@ def solve_activations(A, X, H0=None, *, layout="bin_major", iters=100, eps_mode=
     opts.check_every, opts.stop_rule = int(check_every), _STOPS[stop_rule]
     opts.eps = _EPS_DEFAULT[eps_mode] if eps is None else float(eps)
     opts.l1, opts.tol, opts.init_value = float(l1), float(tol), float(init_value)
+    # tuning/testing knobs: bit 0 disables the fused persistent kernel, bits 8..15 force its
+    # frame-tiles-per-workgroup factor (0 = automatic)
+    opts.reserved = (0 if fused else 1) | ((int(fused_c) & 0xff) << 8)
     if loop_events is not None:     # (torch.cuda.Event, torch.cuda.Event), already created
         opts.ev_loop_start = int(loop_events[0].cuda_event)
         opts.ev_loop_stop = int(loop_events[1].cuda_event)

@@ -24,6 +24,18 @@ pytestmark = pytest.mark.gpu
 
 RTOL64 = 1e-8
 ALGOS = ["factored", "gram", "literal"]
+# "factored" takes the fused persistent kernel when M <= 32 (float64); these variants force the
+# generic two-GEMM factored path and the other frame-tile factors of the fused kernel
+VARIANTS = {"factored": {}, "gram": {}, "literal": {},
+            "factored_generic": {"algo": "factored", "fused": False},
+            "fused_c2": {"algo": "factored", "fused_c": 2},
+            "fused_c4": {"algo": "factored", "fused_c": 4}}
+
+
+def variant_kw(name):
+    kw = {"algo": name}
+    kw.update(VARIANTS[name])
+    return kw
 
 
 def oracle():
@@ -40,7 +52,7 @@ def assert_close64(got, want, what, rtol=RTOL64):
 # S1: _factorize / convert against scikit-learn golden vectors
 # ----------------------------------------------------------------------------------------
 @pytest.mark.parametrize("path", golden_files("sklearn_"), ids=os.path.basename)
-@pytest.mark.parametrize("algo", ALGOS)
+@pytest.mark.parametrize("algo", list(VARIANTS))
 def test_sklearn_golden_solver(path, algo):
     import exemplars_vc_amd as evc
     g = load_golden(path)
@@ -48,7 +60,7 @@ def test_sklearn_golden_solver(path, algo):
     act, info = evc.solve_activations(
         g["W_rows"], g["X_rows"], layout="frame_major", iters=max_iter, eps_mode="zero_replace",
         init="sklearn", l1=l1, check_every=10 if tol > 0 else 0,
-        stop_rule="sklearn" if tol > 0 else "none", tol=tol, algo=algo, info=True)
+        stop_rule="sklearn" if tol > 0 else "none", tol=tol, info=True, **variant_kw(algo))
     assert int(info["n_iter"][0]) == int(g["n_iter"]), (info["n_iter"], g["n_iter"])
     assert_close64(act.T, g["H"], f"H {os.path.basename(path)} {algo}")
     Y = evc.synthesize(g["B_rows"], act, layout="frame_major")
@@ -157,13 +169,14 @@ def test_modes_and_layouts(M, N, T, eps_mode, eps, layout):
     H0 = rng.random((N, T)) + 1e-4
     code = {"add": o.EPS_ADD, "zero_replace": o.EPS_ZERO_REPLACE, "none": o.EPS_NONE, "clamp": o.EPS_CLAMP}[eps_mode]
     want = o.mu_solve(p["A"], p["X"], H0, 40, eps_mode=code, eps=eps, l1=0.0, algo="gram")
-    for algo in ALGOS:
+    for algo in VARIANTS:
+        kw = variant_kw(algo)
         if layout == "bin_major":
             got = evc.solve_activations(p["A"], p["X"], H0, layout=layout, iters=40, eps_mode=eps_mode,
-                                        eps=eps, algo=algo)
+                                        eps=eps, **kw)
         else:
             got = evc.solve_activations(p["A"].T.copy(), p["X"].T.copy(), H0.T.copy(), layout=layout,
-                                        iters=40, eps_mode=eps_mode, eps=eps, algo=algo).T
+                                        iters=40, eps_mode=eps_mode, eps=eps, **kw).T
         assert_close64(got, want, f"{algo} {eps_mode} {layout}")
 
 
@@ -196,8 +209,9 @@ def test_l1_and_zero_frames_and_absorbing_zeros():
     X[:, :4] = 0.0                          # all-zero frames -> exact zeros, then 0-denominators
     H0 = np.random.default_rng(2).random((128, 50)) + 1e-4
     H0[5, :] = 0.0                          # zeros are absorbing under MU
-    for algo in ALGOS:
-        got = evc.solve_activations(p["A"], X, H0, iters=30, eps_mode="zero_replace", l1=0.25, algo=algo)
+    for algo in VARIANTS:
+        got = evc.solve_activations(p["A"], X, H0, iters=30, eps_mode="zero_replace", l1=0.25,
+                                    **variant_kw(algo))
         want = o.mu_solve(p["A"], X, H0, 30, eps_mode=o.EPS_ZERO_REPLACE, eps=o.SK_EPSILON, l1=0.25)
         assert_close64(got, want, "l1")
         assert (got[5] == 0).all() and (got[:, :4] == 0).all()
