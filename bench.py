@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""bench.py - spectral frames/sec converted on the exemplar-NMF activation path.
+
+A "step" is one pass of the hot path over one batch of synthetic utterances already
+resident in HBM: activation solve (K multiplicative updates against the fixed dictionary A,
+scikit-learn semantics as called by 04_align_n_nmf.py: constant init, zero->EPSILON guard,
+fixed K, no early stop) followed by the synthesis Y = B H.  Default workload is BASELINE.json
+configs[1] ("C2"): M=25 bins, N=4096 exemplars, K=100, float64, 96 utterances x 688 frames.
+
+  python bench.py [--gpus N --steps K --warmup W]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+N>1: one process per GPU, utterances sharded (independent shards, no data-path
+collective; torch.distributed is used for the barrier and the max-over-ranks only).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# MI355X peaks (/opt/skills/guides/MI355X_MICROARCH.md: FP64 vector/matrix 78.6 TFLOP/s is the
+# public datasheet number quoted in SURVEY.md section 8d; HBM3E 8 TB/s spec)
+PEAK_F64_TFLOPS = 78.6
+PEAK_F32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def algorithmic_flops_per_frame(M, N, K, Mb, algo):
+    """flops per frame for the algebra actually executed."""
+    if algo == "gram":
+        return K * (2 * N * N + 3 * N) + 2 * M * N + 2 * Mb * N
+    if algo == "literal":
+        return K * (2 * N * N + 2 * M * N + 3 * N) + 2 * Mb * N
+    return K * (4 * M * N + 3 * N) + 2 * M * N + 2 * Mb * N
+
+
+def loop_flops_per_frame(M, N, K, algo):
+    """the part of the above executed inside the iteration loop (the timed dominant kernel)"""
+    if algo == "gram":
+        return K * (2 * N * N + 3 * N)
+    if algo == "literal":
+        return K * (2 * N * N + 2 * M * N + 3 * N)
+    return K * (4 * M * N + 3 * N)
+
+
+def cpu_baseline(M, N, K, seed, budget_frames):
+    """The reference CPU path on this box's host cores, on a bounded sample of the same
+    workload: one utterance (688 frames) through the oracle's restatement of what
+    04_align_n_nmf.py executes (scikit-learn MU, Gram and numerator hoisted), float64, all
+    BLAS threads.  kind = "port" (the oracle; bit-exact against scikit-learn 1.7.2)."""
+    from oracle import evc_oracle as o
+    T = budget_frames
+    p = o.synth_problem(M, N, T, seed=seed)
+    X_rows = np.ascontiguousarray(p["X"].T)
+    W_rows = np.ascontiguousarray(p["A"].T)
+    B_rows = np.ascontiguousarray(p["B"].T)
+    t0 = time.perf_counter()
+    act, n_iter, _ = o.sklearn_mu_fixed_dictionary(X_rows, W_rows, max_iter=K, tol=0.0)
+    Y = o.s4_convert(act.T, B_rows)
+    dt = time.perf_counter() - t0
+    out = {"value": T / dt, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
+           "sample": f"1 utterance of {T} frames, M={M} N={N} K={K}, float64, oracle restatement of the "
+                     f"scikit-learn MU call of 04_align_n_nmf.py:212 + np.matmul(H.T,B); {dt:.2f} s wall",
+           "seconds": dt}
+    try:
+        import threadpoolctl
+        info = threadpoolctl.threadpool_info()
+        out["blas"] = [{"api": i.get("internal_api"), "threads": i.get("num_threads")} for i in info]
+        out["cores"] = max([i.get("num_threads", 1) for i in info] + [1])
+    except Exception:
+        pass
+    # pymf-literal (Gram and numerator recomputed per iteration) on a quarter of the frames
+    Tq = max(16, T // 4)
+    H0 = np.random.default_rng(1).random((N, Tq)) + 1e-4
+    t0 = time.perf_counter()
+    o.pymf_factorize(p["X"][:, :Tq], p["A"], H0, niter=K, compute_err=False)
+    dtl = time.perf_counter() - t0
+    out["pymf_literal_frames_per_s"] = Tq / dtl
+    return out, (p, act, Y)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--bins", type=int, default=25)
+    ap.add_argument("--exemplars", type=int, default=4096)
+    ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--utterances", type=int, default=96)
+    ap.add_argument("--frames", type=int, default=688, help="frames per utterance")
+    ap.add_argument("--algo", default="factored", choices=["factored", "gram", "literal"])
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--no-fused", action="store_true")
+    ap.add_argument("--fused-c", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--cpu-frames", type=int, default=688)
+    args = ap.parse_args()
+
+    import torch
+    import exemplars_vc_amd as evc
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    M, N, K = args.bins, args.exemplars, args.iters
+    U, Tu = args.utterances, args.frames
+    T = U * Tu
+    tdt = torch.float64 if args.dtype == "f64" else torch.float32
+
+    # synthetic shard of this rank (SURVEY.md 8d recipe, generated on the device in float64):
+    # unit-L2 dictionary columns, ~8 active exemplars per frame, X = A H* + 1e-6
+    g = torch.Generator(device=dev)
+    g.manual_seed(20190131)
+    A = torch.rand(N, M, generator=g, device=dev, dtype=torch.float64) + 1e-3     # frames-as-rows
+    A /= A.norm(dim=1, keepdim=True)
+    B = torch.rand(N, M, generator=g, device=dev, dtype=torch.float64) + 1e-3
+    B /= B.norm(dim=1, keepdim=True)
+    g.manual_seed(1000 + rank)
+    Hs = torch.rand(T, N, generator=g, device=dev, dtype=torch.float64)
+    Hs *= (torch.rand(T, N, generator=g, device=dev, dtype=torch.float64) < (8.0 / N))
+    X = Hs @ A + 1e-6
+    del Hs
+    A, B, X = A.to(tdt), B.to(tdt), X.to(tdt).contiguous()
+    offs = np.arange(U + 1, dtype=np.int32) * Tu
+    H = torch.empty(T, N, dtype=tdt, device=dev)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(); ev1.record()          # force creation of the underlying hipEvent_t
+    torch.cuda.synchronize()
+    loop_ms = []
+
+    def step(timed):
+        evc.solve_activations(A, X, layout="frame_major", iters=K, eps_mode="zero_replace",
+                              init="sklearn", algo=args.algo, utt_offsets=offs, out=H,
+                              fused=not args.no_fused, fused_c=args.fused_c,
+                              loop_events=(ev0, ev1))
+        Y = evc.synthesize(B, H, layout="frame_major")
+        if timed:
+            ev1.synchronize()
+            loop_ms.append(ev0.elapsed_time(ev1))
+        return Y
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        Y = step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        value = world * T * args.steps / elapsed
+        loop_s = float(np.mean(loop_ms)) / 1e3
+        fl_loop = loop_flops_per_frame(M, N, K, args.algo) * T
+        achieved = fl_loop / loop_s / 1e12
+        peak = PEAK_F64_TFLOPS if args.dtype == "f64" else PEAK_F32_TFLOPS
+        fused = args.algo == "factored" and args.dtype == "f64" and M <= 32 and not args.no_fused
+        res = {
+            "metric": "spectral frames/sec converted (100 NMF iters, N=4096 dict)",
+            "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"C2 (BASELINE configs[1]): SF1->TF1-shaped dictionary, M={M} bins, "
+                                   f"N={N} exemplars, K={K} MU iterations, {U} utterances x {Tu} frames "
+                                   f"= {T} frames per GPU per step, solve + synthesis B*H",
+                       "algo": args.algo, "kernel": "k_fused_mu (persistent, 1 launch per step)" if fused
+                       else "k_gemm_nt(+mu epilogue), launches per iteration",
+                       "frames_per_gpu": T, "parallelism": f"utterance shards x{world}"},
+            "roofline": {
+                "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                "frac": achieved / peak, "traffic": None,
+                "kernel": "iteration loop (k_fused_mu)" if fused else "iteration loop (k_gemm_nt family)",
+                "launch_ms": 1e3 * loop_s,
+                "algorithmic_flops_per_launch": fl_loop,
+                "note": "achieved = algorithmic flops of the executed algebra (K*(4MN+3N) per frame "
+                        "for FACTORED) / HIP-event time of the loop launches on the launch stream",
+            },
+            "algorithmic_gflop_per_frame": algorithmic_flops_per_frame(M, N, K, M, args.algo) / 1e9,
+        }
+        if not args.no_cpu:
+            cpu, (p, act_cpu, Y_cpu) = cpu_baseline(M, N, K, 20190131, args.cpu_frames)
+            res["cpu_baseline"] = cpu
+            res["speedup_vs_cpu"] = value / cpu["value"]
+            # parity of the GPU path on the very sample the CPU leg timed
+            Xs = np.ascontiguousarray(p["X"].T)
+            Hg = evc.solve_activations(np.ascontiguousarray(p["A"].T), Xs, layout="frame_major", iters=K,
+                                       eps_mode="zero_replace", init="sklearn", algo=args.algo,
+                                       dtype=args.dtype, fused=not args.no_fused)
+            Yg = evc.synthesize(np.ascontiguousarray(p["B"].T).astype(Hg.dtype), Hg, layout="frame_major")
+            nz = act_cpu != 0
+            res["parity"] = {
+                "H_max_rel_err": float(np.max(np.abs(Hg[nz] - act_cpu[nz]) / act_cpu[nz])),
+                "Y_max_rel_err": float(np.max(np.abs(Yg - Y_cpu) / np.abs(Y_cpu))),
+                "rtol_required": 1e-4,
+            }
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

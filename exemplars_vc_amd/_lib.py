@@ -51,6 +51,11 @@ def lib():
         raise RuntimeError(
             f"{LIB_PATH} not found: build it with `python -m exemplars_vc_amd.csrc.build` "
             "(hipcc, gfx950).  exemplars_vc_amd has no CPU fallback.")
+    # PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64; import it FIRST so that
+    # libevc_hip.so binds to the HIP runtime torch already initialised (one runtime per process:
+    # shared device context, interoperable streams and events).  Loaded the other way round, two
+    # HSA runtimes end up in the process and the second one sees no device.
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     L.evc_version.restype = C.c_int
     L.evc_strerror.restype = C.c_char_p

@@ -127,7 +127,7 @@ int solve_fused(const Workspace<T>& w, const Dims& d, const evc_solve_opts& o, i
 template <>
 int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_solve_opts& o, int n_utt,
                         hipStream_t s) {
-    const int c_override = (o.reserved >> 8) & 0xff;
+    const int c_override = (o.reserved >> 8) & 0xffff;   // C | variant << 8
     HIP_TRY(fused_pack(w.fl, w.fb, w.At, d.Mk, w.Xt, d.Mk, w.H0, d.Np, s));
     int first = 1;
     if (o.check_every > 0 && o.stop_rule == EVC_STOP_SKLEARN) {   // error_at_init

@@ -25,6 +25,8 @@
 // A^T (A H) (SURVEY.md section 7 "Which algebra").
 #include "evc_internal.h"
 
+#include <type_traits>
+
 namespace evc {
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
@@ -100,15 +102,91 @@ struct FusedArgs {
     double eps, l1;
 };
 
-constexpr int FW = 8;  // wavefronts per workgroup
+// The update with the guard mode as a compile-time constant (the switch is hoisted out of the
+// sweep).  On gfx950 an f64 MFMA and any VALU instruction of the same SIMD do not overlap
+// (tools/ubench/mfma_valu_f64.hip: times add), so the VALU instruction count of this function is
+// directly MFMA time lost.  Hence:
+//   * l1 (and pymf's additive eps) are folded into the initial value of the D accumulator, so
+//     `dacc` arrives as the finished denominator sum;
+//   * one unsigned range test per tile (high words, v_max3) decides between the fast path and the
+//     exact path.  Fast path = every denominator is a normal number in [lo, 2^928): then neither
+//     the ==0 replacement nor the clamp can fire, and the quotient is formed as
+//     r = v_rcp_f64(den) (~23 bits), one Newton step (~46 bits), q = num*r, one residual
+//     correction (error ~ (2^-46)^2 -> correctly rounded to ~1 ulp): 7 VALU per element, no
+//     v_div_scale/fmas/fixup and no selects;
+//   * the exact path (zero / denormal / huge / NaN denominators, and the unguarded NONE mode
+//     always) applies the guard literally and divides with IEEE semantics, so inf/NaN behaviour
+//     is the reference's.
+__device__ __forceinline__ double fast_div(double num, double den) {
+    double r = __builtin_amdgcn_rcp(den);
+    const double e = __builtin_fma(-den, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double qv = num * r;
+    const double rem = __builtin_fma(-den, qv, num);
+    return __builtin_fma(rem, r, qv);
+}
+__device__ __forceinline__ unsigned hi_word(double x) { return (unsigned)(__double_as_longlong(x) >> 32); }
+// lowest admissible high word for the fast path: 2^-928, or one binade above eps when clamping
+__device__ __forceinline__ unsigned fast_lo(int mode, double eps) {
+    unsigned lo = 0x05F00000u;
+    if (mode == EVC_EPS_CLAMP && eps > 0) {
+        const unsigned e = hi_word(eps) + 0x00200000u;
+        lo = e > lo ? e : lo;
+    }
+    return lo;
+}
+template <int MODE>
+__device__ __forceinline__ void mu_tile(double (&h)[4], const f64x4& p, const f64x4& dacc, double eps,
+                                        unsigned lo) {
+    constexpr bool MUL_FIRST = (MODE == EVC_EPS_ADD || MODE == EVC_EPS_NONE);   // (h*p)/den vs h*(p/den)
+    const unsigned span = 0x79F00000u - lo;
+    unsigned worst = max(max(hi_word(dacc[0]) - lo, hi_word(dacc[1]) - lo),
+                         max(hi_word(dacc[2]) - lo, hi_word(dacc[3]) - lo));
+    if (MODE != EVC_EPS_NONE && __builtin_expect(__all(worst < span), 1)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double qv = fast_div(MUL_FIRST ? h[r] * p[r] : p[r], dacc[r]);
+            h[r] = MUL_FIRST ? qv : h[r] * qv;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double dn = dacc[r];
+            if (MODE == EVC_EPS_ZERO_REPLACE) dn = (dn == 0.0) ? eps : dn;  // sklearn _nmf.py:620
+            if (MODE == EVC_EPS_CLAMP) dn = (dn > eps) ? dn : eps;          // deComP
+            const double qv = (MUL_FIRST ? h[r] * p[r] : p[r]) / dn;
+            h[r] = MUL_FIRST ? qv : h[r] * qv;
+        }
+    }
+}
 
-template <int MSTEPS, int C>
-__global__ __launch_bounds__(FW * 64) void k_fused_mu(FusedArgs a) {
+// Registers of one 16-exemplar dictionary tile (both operand orders) and of the C activation
+// tiles that go with it; two of these ping-pong so that tile j+NW is in flight while tile j is
+// on the matrix cores.
+template <int MSTEPS, int C> struct TileRegs {
+    static constexpr int MT = MSTEPS > 4 ? 2 : 1;
+    double a1[MSTEPS];
+    double a2[MT][4];
+    f64x2 h01[C], h23[C];
+};
+
+// DBG (timing experiments only, results are wrong): bit 0 = no H traffic, bit 1 = no dictionary loads
+template <int MSTEPS, int C, int NW, bool PF, int DBG = 0>
+__global__ __launch_bounds__(NW * 64) void k_fused_mu(FusedArgs a) {
     constexpr int MT = MSTEPS > 4 ? 2 : 1;
-    extern __shared__ double red[];      // [FW][C][MT][4][64]
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    constexpr int E = C * MT * 4 * 64;           // doubles in one V (accumulator order)
+    extern __shared__ double lds[];
+    double* red = lds;                           // [NW][E]   partial V' of every wavefront
+    double* vL = lds + NW * E;                   // [C][MT*4][64]  V, B-operand order
+    double* xL = vL + E;                         // [C][MT*4][64]  X, B-operand order
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar loop and addresses
     const int q = lane >> 4;
     const long tt0 = (long)blockIdx.x * C;
+    const double* __restrict__ A1p = a.A1p;
+    const double* __restrict__ A2p = a.A2p;
+    f64x2* __restrict__ Hp = a.Hp;
+    const int NT = a.NT;
 
     // which of my frames take part in this launch
     bool live[C];
@@ -123,38 +201,52 @@ __global__ __launch_bounds__(FW * 64) void k_fused_mu(FusedArgs a) {
     }
     if (!__syncthreads_or(any)) return;
 
-    double xf[C][MSTEPS], vf[C][MSTEPS];
-#pragma unroll
-    for (int c = 0; c < C; ++c)
-#pragma unroll
-        for (int s = 0; s < MSTEPS; ++s) {
-            const bool in = tt0 + c < a.TT;
-            const long o = ((tt0 + c) * MSTEPS + s) * 64 + lane;
-            xf[c][s] = in ? a.Xp[o] : 0.0;
-            vf[c][s] = (in && !a.first) ? a.Vp[((tt0 + c) * 8 + s) * 64 + lane] : 0.0;
-        }
+    // stage X (and the carried V) in LDS
+    for (int e = tid; e < E; e += NW * 64) {
+        const int c = e / (MT * 256), s = (e >> 6) % (MT * 4), l = e & 63;
+        const bool in = (tt0 + c < a.TT) && s < MSTEPS;
+        xL[e] = in ? a.Xp[((tt0 + c) * MSTEPS + s) * 64 + l] : 0.0;
+        vL[e] = (in && !a.first) ? a.Vp[((tt0 + c) * 8 + s) * 64 + l] : 0.0;
+    }
+    __syncthreads();
 
-    // combine the 8 wavefronts' partial V' (fixed order) into the B-operand registers
+    typedef TileRegs<MSTEPS, C> Regs;
+    auto load_tile = [&](Regs& R, int j, bool with_a1) {
+        const int ja = (DBG & 2) ? w : j;
+        if (with_a1) {
+#pragma unroll
+            for (int s = 0; s < MSTEPS; ++s) R.a1[s] = A1p[((long)ja * MSTEPS + s) * 64 + lane];
+        }
+#pragma unroll
+        for (int u = 0; u < MT; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) R.a2[u][r] = A2p[(((long)ja * MT + u) * 4 + r) * 64 + lane];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            if (DBG & 1) { R.h01[c] = f64x2{1e-3, 2e-3}; R.h23[c] = f64x2{1e-3, 3e-3}; continue; }
+            if (tt0 + c >= a.TT) { R.h01[c] = f64x2{0, 0}; R.h23[c] = f64x2{0, 0}; continue; }
+            const long hb = ((tt0 + c) * NT + j) * 128 + lane;
+            if (DBG & 8) { R.h01[c] = __builtin_nontemporal_load(&Hp[hb]); R.h23[c] = __builtin_nontemporal_load(&Hp[hb + 64]); }
+            else { R.h01[c] = Hp[hb]; R.h23[c] = Hp[hb + 64]; }
+        }
+    };
+
+    // V' partials -> LDS -> each wavefront sums a slice over the NW partials in fixed order -> vL
     auto reduce_v = [&](f64x4 (&vn)[C][MT]) {
-        __syncthreads();                 // previous readers of `red` are done
 #pragma unroll
         for (int c = 0; c < C; ++c)
 #pragma unroll
             for (int u = 0; u < MT; ++u)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    red[(((w * C + c) * MT + u) * 4 + r) * 64 + lane] = vn[c][u][r];
+                for (int r = 0; r < 4; ++r) red[w * E + ((c * MT + u) * 4 + r) * 64 + lane] = vn[c][u][r];
         __syncthreads();
+        for (int e = w * 64 + lane; e < E; e += NW * 64) {
+            double acc = 0.0;
 #pragma unroll
-        for (int c = 0; c < C; ++c)
-#pragma unroll
-            for (int s = 0; s < MSTEPS; ++s) {
-                double acc = 0.0;
-#pragma unroll
-                for (int ww = 0; ww < FW; ++ww)
-                    acc += red[(((ww * C + c) * MT + (s >> 2)) * 4 + (s & 3)) * 64 + lane];
-                vf[c][s] = acc;
-            }
+            for (int ww = 0; ww < NW; ++ww) acc += red[ww * E + e];
+            vL[e] = acc;
+        }
+        __syncthreads();
     };
 
     if (a.first) {      // V = A H for the incoming activations
@@ -163,90 +255,135 @@ __global__ __launch_bounds__(FW * 64) void k_fused_mu(FusedArgs a) {
         for (int c = 0; c < C; ++c)
 #pragma unroll
             for (int u = 0; u < MT; ++u) vn[c][u] = f64x4{0, 0, 0, 0};
-        for (int j = w; j < a.NT; j += FW) {
-            double a2[MT][4];
-#pragma unroll
-            for (int u = 0; u < MT; ++u)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) a2[u][r] = a.A2p[(((long)j * MT + u) * 4 + r) * 64 + lane];
+        for (int j = w; j < NT; j += NW) {
+            Regs R;
+            load_tile(R, j, false);
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                if (tt0 + c >= a.TT) continue;
-                const long hb = ((tt0 + c) * a.NT + j) * 128 + lane;
-                const f64x2 h01 = a.Hp[hb], h23 = a.Hp[hb + 64];
-                const double h[4] = {h01[0], h01[1], h23[0], h23[1]};
+                const double h[4] = {R.h01[c][0], R.h01[c][1], R.h23[c][0], R.h23[c][1]};
 #pragma unroll
                 for (int u = 0; u < MT; ++u)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) vn[c][u] = Mma<double>::mma(a2[u][r], h[r], vn[c][u]);
+                    for (int r = 0; r < 4; ++r) vn[c][u] = Mma<double>::mma(R.a2[u][r], h[r], vn[c][u]);
             }
         }
         reduce_v(vn);
     }
 
-    for (int it = 0; it < a.iters; ++it) {
-        f64x4 vn[C][MT];
+    // frames that are frozen / padded, or a ragged last exemplar tile, need per-element selects;
+    // everything else runs the select-free sweep
+    bool all_live = true;
 #pragma unroll
-        for (int c = 0; c < C; ++c)
-#pragma unroll
-            for (int u = 0; u < MT; ++u) vn[c][u] = f64x4{0, 0, 0, 0};
+    for (int c = 0; c < C; ++c) all_live = all_live && live[c];
+    const bool masked = !__syncthreads_and(all_live) || (a.N & 15) != 0;
+    const double eps = a.eps;
 
-        for (int j = w; j < a.NT; j += FW) {
-            double a1[MSTEPS], a2[MT][4];
+    auto sweep = [&](auto mode_tag, auto masked_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        // l1 (sklearn _nmf.py:615-617) and pymf's +eps (nmf.py:68) ride in the accumulator's start value
+        const double d0 = a.l1 + (MODE == EVC_EPS_ADD ? a.eps : 0.0);
+        const f64x4 dinit = {d0, d0, d0, d0};
+        const unsigned lo = fast_lo(MODE, eps);
+        for (int it = 0; it < a.iters; ++it) {
+            f64x4 vn[C][MT];
 #pragma unroll
-            for (int s = 0; s < MSTEPS; ++s) a1[s] = a.A1p[((long)j * MSTEPS + s) * 64 + lane];
+            for (int c = 0; c < C; ++c)
 #pragma unroll
-            for (int u = 0; u < MT; ++u)
+                for (int u = 0; u < MT; ++u) vn[c][u] = f64x4{0, 0, 0, 0};
+
+            auto compute_tile = [&](const Regs& R, int j) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) a2[u][r] = a.A2p[(((long)j * MT + u) * 4 + r) * 64 + lane];
-            const int n0 = 16 * j + 4 * q;
+                for (int c = 0; c < C; ++c) {
+                    if (MASKED && tt0 + c >= a.TT) continue;     // uniform
+                    f64x4 d = dinit, p = {0, 0, 0, 0};
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-                if (tt0 + c >= a.TT) continue;     // uniform
-                const long hb = ((tt0 + c) * a.NT + j) * 128 + lane;
-                const f64x2 h01 = a.Hp[hb], h23 = a.Hp[hb + 64];
-                f64x4 d = {0, 0, 0, 0}, p = {0, 0, 0, 0};
+                    for (int s = 0; s < MSTEPS; ++s) {
+                        d = Mma<double>::mma(R.a1[s], vL[(c * MT * 4 + s) * 64 + lane], d);
+                        p = Mma<double>::mma(R.a1[s], xL[(c * MT * 4 + s) * 64 + lane], p);
+                    }
+                    double h[4] = {R.h01[c][0], R.h01[c][1], R.h23[c][0], R.h23[c][1]};
+                    if (DBG & 4) {
 #pragma unroll
-                for (int s = 0; s < MSTEPS; ++s) {
-                    d = Mma<double>::mma(a1[s], vf[c][s], d);
-                    p = Mma<double>::mma(a1[s], xf[c][s], p);
+                        for (int r = 0; r < 4; ++r) h[r] = h[r] * p[r] + d[r];
+                    } else if (MASKED) {
+                        double hn[4] = {h[0], h[1], h[2], h[3]};
+                        mu_tile<MODE>(hn, p, d, eps, lo);
+                        const int n0 = 16 * j + 4 * q;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const double v = (n0 + r < a.N) ? hn[r] : 0.0;   // exemplar padding stays 0
+                            h[r] = live[c] ? v : h[r];                      // stopped utterances are frozen
+                        }
+                    } else {
+                        mu_tile<MODE>(h, p, d, eps, lo);
+                    }
+                    const long hb = ((tt0 + c) * NT + j) * 128 + lane;
+                    if (DBG & 8) {
+                        __builtin_nontemporal_store(f64x2{h[0], h[1]}, &Hp[hb]);
+                        __builtin_nontemporal_store(f64x2{h[2], h[3]}, &Hp[hb + 64]);
+                    } else if (!(DBG & 1) || h[0] == 123.456) {
+                        Hp[hb] = f64x2{h[0], h[1]};
+                        Hp[hb + 64] = f64x2{h[2], h[3]};
+                    }
+#pragma unroll
+                    for (int u = 0; u < MT; ++u)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) vn[c][u] = Mma<double>::mma(R.a2[u][r], h[r], vn[c][u]);
                 }
-                double h[4] = {h01[0], h01[1], h23[0], h23[1]};
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    double hn = mu_update<double>(h[r], p[r], d[r], a.eps_mode, a.eps, a.l1);
-                    hn = (n0 + r < a.N) ? hn : 0.0;          // exemplar padding stays exactly 0
-                    h[r] = live[c] ? hn : h[r];              // stopped utterances are frozen
+            };
+
+            if (PF) {
+                Regs R0, R1;
+                int j = w;
+                if (j < NT) load_tile(R0, j, true);
+                for (; j < NT; j += 2 * NW) {
+                    const int j1 = j + NW, j2 = j + 2 * NW;
+                    if (j1 < NT) load_tile(R1, j1, true);
+                    compute_tile(R0, j);
+                    if (j1 < NT) {
+                        if (j2 < NT) load_tile(R0, j2, true);
+                        compute_tile(R1, j1);
+                    }
                 }
-                a.Hp[hb] = f64x2{h[0], h[1]};
-                a.Hp[hb + 64] = f64x2{h[2], h[3]};
-#pragma unroll
-                for (int u = 0; u < MT; ++u)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) vn[c][u] = Mma<double>::mma(a2[u][r], h[r], vn[c][u]);
+            } else {
+                for (int j = w; j < NT; j += NW) {
+                    Regs R;
+                    load_tile(R, j, true);
+                    compute_tile(R, j);
+                }
             }
+            reduce_v(vn);
         }
-        reduce_v(vn);
+    };
+    auto run_mode = [&](auto mode_tag) {
+        if (masked) sweep(mode_tag, std::true_type{});
+        else sweep(mode_tag, std::false_type{});
+    };
+    switch (a.eps_mode) {
+        case EVC_EPS_ADD: run_mode(std::integral_constant<int, EVC_EPS_ADD>{}); break;
+        case EVC_EPS_ZERO_REPLACE: run_mode(std::integral_constant<int, EVC_EPS_ZERO_REPLACE>{}); break;
+        case EVC_EPS_CLAMP: run_mode(std::integral_constant<int, EVC_EPS_CLAMP>{}); break;
+        default: run_mode(std::integral_constant<int, EVC_EPS_NONE>{}); break;
     }
 
-    if (w == 0) {
+    // carry V to the next launch; per-frame squared residual of the final activations
+    for (int e = tid; e < E; e += NW * 64) {
+        const int c = e / (MT * 256), s = (e >> 6) % (MT * 4), l = e & 63;
+        if (tt0 + c < a.TT && s < MSTEPS) a.Vp[((tt0 + c) * 8 + s) * 64 + l] = vL[e];
+    }
+    if (a.write_err && w < C && tt0 + w < a.TT) {
+        const int c = w;
+        double e = 0.0;
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
-            if (tt0 + c >= a.TT) continue;
-            double e = 0.0;
-#pragma unroll
-            for (int s = 0; s < MSTEPS; ++s) {
-                a.Vp[((tt0 + c) * 8 + s) * 64 + lane] = vf[c][s];
-                const double df = xf[c][s] - vf[c][s];
-                e += df * df;
-            }
-            if (a.write_err) {           // sum over the 4 lane groups holding one frame's bins
-                e += __shfl_xor(e, 16, 64);
-                e += __shfl_xor(e, 32, 64);
-                const long t = 16 * (tt0 + c) + lane;
-                if (lane < 16 && t < a.T_) a.err2[t] = e;
-            }
+        for (int s = 0; s < MSTEPS; ++s) {
+            const double df = xL[(c * MT * 4 + s) * 64 + lane] - vL[(c * MT * 4 + s) * 64 + lane];
+            e += df * df;
         }
+        e += __shfl_xor(e, 16, 64);      // the 4 lane groups hold one frame's bins
+        e += __shfl_xor(e, 32, 64);
+        const long t = 16 * (tt0 + c) + lane;
+        if (lane < 16 && t < a.T_) a.err2[t] = e;
     }
 }
 
@@ -294,31 +431,32 @@ hipError_t fused_unpack(const FusedLayout& f, const FusedBuffers& b, double* Ht,
     return hipGetLastError();
 }
 
-template <int MSTEPS, int C>
+template <int MSTEPS, int C, int NW, bool PF, int DBG = 0>
 static hipError_t launch_fused(const FusedArgs& a, hipStream_t s) {
     constexpr int MT = MSTEPS > 4 ? 2 : 1;
-    const size_t lds = (size_t)FW * C * MT * 4 * 64 * sizeof(double);
+    constexpr int E = C * MT * 4 * 64;
+    const size_t lds = (size_t)(NW + 2) * E * sizeof(double);
     const unsigned grid = (unsigned)((a.TT + C - 1) / C);
     if (lds > 48 * 1024) {   // per-launch, so that no mutable global state is kept
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_mu<MSTEPS, C>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_mu<MSTEPS, C, NW, PF, DBG>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_fused_mu<MSTEPS, C>), dim3(grid), dim3(FW * 64), lds, s, a);
+    hipLaunchKernelGGL((k_fused_mu<MSTEPS, C, NW, PF, DBG>), dim3(grid), dim3(NW * 64), lds, s, a);
     return hipGetLastError();
 }
 
-template <int C>
+template <int C, int NW, bool PF>
 static hipError_t dispatch_msteps(int msteps, const FusedArgs& a, hipStream_t s) {
     switch (msteps) {
-        case 1: return launch_fused<1, C>(a, s);
-        case 2: return launch_fused<2, C>(a, s);
-        case 3: return launch_fused<3, C>(a, s);
-        case 4: return launch_fused<4, C>(a, s);
-        case 5: return launch_fused<5, C>(a, s);
-        case 6: return launch_fused<6, C>(a, s);
-        case 7: return launch_fused<7, C>(a, s);
-        case 8: return launch_fused<8, C>(a, s);
+        case 1: return launch_fused<1, C, NW, PF>(a, s);
+        case 2: return launch_fused<2, C, NW, PF>(a, s);
+        case 3: return launch_fused<3, C, NW, PF>(a, s);
+        case 4: return launch_fused<4, C, NW, PF>(a, s);
+        case 5: return launch_fused<5, C, NW, PF>(a, s);
+        case 6: return launch_fused<6, C, NW, PF>(a, s);
+        case 7: return launch_fused<7, C, NW, PF>(a, s);
+        case 8: return launch_fused<8, C, NW, PF>(a, s);
         default: return hipErrorInvalidValue;
     }
 }
@@ -329,20 +467,35 @@ int fused_pick_c(int T_) {
     return 1;                     // few frames: as many workgroups as possible
 }
 
+// variant: bits 0..7 frame tiles per workgroup (0 = automatic), bits 8..15 tuning variant id
 hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttState& u, int N, int T_,
                          int iters, int first, int write_err, double* err2, int eps_mode, double eps,
-                         double l1, int c_override, hipStream_t s) {
+                         double l1, int variant, hipStream_t s) {
     FusedArgs a;
     a.A1p = b.A1p; a.A2p = b.A2p; a.Xp = b.Xp; a.Hp = reinterpret_cast<f64x2*>(b.Hp); a.Vp = b.Vp;
     a.err2 = err2; a.frame_utt = u.frame_utt; a.active = u.active;
     a.NT = f.NT; a.TT = f.TT; a.N = N; a.T_ = T_;
     a.iters = iters; a.first = first; a.write_err = write_err;
     a.eps_mode = eps_mode; a.eps = eps; a.l1 = l1;
-    const int C = c_override > 0 ? c_override : fused_pick_c(T_);
+    const int c_req = variant & 0xff, vid = (variant >> 8) & 0xff;
+    const int C = c_req > 0 ? c_req : fused_pick_c(T_);
+    if (vid != 0 && f.msteps == 7) {          // tuning variants exist for the C2 shape only
+        switch (vid * 10 + C) {
+            case 11: return launch_fused<7, 1, 8, true>(a, s);
+            case 21: return launch_fused<7, 1, 16, false>(a, s);
+            case 31: return launch_fused<7, 1, 4, false>(a, s);
+            case 32: return launch_fused<7, 2, 4, false>(a, s);
+            case 41: return launch_fused<7, 1, 8, false, 8>(a, s);     // nontemporal H accesses
+            case 51: return launch_fused<7, 1, 8, false, 1>(a, s);     // no H traffic
+            case 61: return launch_fused<7, 1, 8, false, 2>(a, s);     // no dictionary loads
+            case 71: return launch_fused<7, 1, 8, false, 3>(a, s);     // neither
+            case 81: return launch_fused<7, 1, 8, false, 7>(a, s);     // neither, no division
+            default: return hipErrorInvalidValue;
+        }
+    }
     switch (C) {
-        case 1: return dispatch_msteps<1>(f.msteps, a, s);
-        case 2: return dispatch_msteps<2>(f.msteps, a, s);
-        case 4: return dispatch_msteps<4>(f.msteps, a, s);
+        case 1: return dispatch_msteps<1, 8, false>(f.msteps, a, s);
+        case 2: return dispatch_msteps<2, 8, false>(f.msteps, a, s);
         default: return hipErrorInvalidValue;
     }
 }
