@@ -132,7 +132,7 @@ int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_sol
     int first = 1;
     if (o.check_every > 0 && o.stop_rule == EVC_STOP_SKLEARN) {   // error_at_init
         HIP_TRY(fused_iterate(w.fl, w.fb, w.u, d.N, d.T_, 0, 1, 1, w.err2, o.eps_mode, o.eps, o.l1,
-                              c_override, s));
+                              c_override, 1, s));
         HIP_TRY(utt_check(w.err2, w.u, n_utt, 0, o.check_every, o.stop_rule, o.tol, s));
         first = 0;
     }
@@ -143,7 +143,7 @@ int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_sol
         bool check = false;
         if (o.check_every > 0 && n >= o.check_every) { n = o.check_every; check = true; }
         HIP_TRY(fused_iterate(w.fl, w.fb, w.u, d.N, d.T_, n, first, check ? 1 : 0, w.err2, o.eps_mode,
-                              o.eps, o.l1, c_override, s));
+                              o.eps, o.l1, c_override, o.stop_rule == EVC_STOP_NONE ? 1 : 0, s));
         first = 0;
         done += n;
         if (check)

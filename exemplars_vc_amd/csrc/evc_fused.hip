@@ -23,17 +23,9 @@
 //
 // Reference arithmetic: sklearn _nmf.py:526-556,612-631 / pymf nmf.py:66-70 re-associated as
 // A^T (A H) (SURVEY.md section 7 "Which algebra").
-#include "evc_internal.h"
-
-#include <type_traits>
+#include "evc_fused_common.h"
 
 namespace evc {
-
-typedef double f64x2 __attribute__((ext_vector_type(2)));
-
-__host__ __device__ inline int fused_msteps(int M) { return M <= 16 ? (M + 3) / 4 : 4 + (M - 16 + 3) / 4; }
-// bin handled by k-step s for lane group q
-__device__ __forceinline__ int bin_of(int s, int q) { return 16 * (s >> 2) + q + 4 * (s & 3); }
 
 // ------------------------------------------------------------------------------------------
 // packing (runs once per call)
@@ -82,84 +74,6 @@ __global__ void k_pack_h(double* __restrict__ Ht, int ldh, long TTp, int NT, f64
     else *reinterpret_cast<f64x2*>(src) = Hp[gid];
 }
 
-// ------------------------------------------------------------------------------------------
-// the persistent kernel
-// ------------------------------------------------------------------------------------------
-struct FusedArgs {
-    const double* A1p;
-    const double* A2p;
-    const double* Xp;
-    f64x2* Hp;
-    double* Vp;              // [TTp][8][64] V in B-operand order, carried between launches
-    double* err2;            // [T] per-frame squared residual (written when write_err)
-    const int* frame_utt;
-    const int* active;
-    int NT, TT, N, T_;
-    int iters;               // updates performed by this launch
-    int first;               // 1: V is computed from H by a pre-pass, 0: V is loaded from Vp
-    int write_err;
-    int eps_mode;
-    double eps, l1;
-};
-
-// The update with the guard mode as a compile-time constant (the switch is hoisted out of the
-// sweep).  On gfx950 an f64 MFMA and any VALU instruction of the same SIMD do not overlap
-// (tools/ubench/mfma_valu_f64.hip: times add), so the VALU instruction count of this function is
-// directly MFMA time lost.  Hence:
-//   * l1 (and pymf's additive eps) are folded into the initial value of the D accumulator, so
-//     `dacc` arrives as the finished denominator sum;
-//   * one unsigned range test per tile (high words, v_max3) decides between the fast path and the
-//     exact path.  Fast path = every denominator is a normal number in [lo, 2^928): then neither
-//     the ==0 replacement nor the clamp can fire, and the quotient is formed as
-//     r = v_rcp_f64(den) (~23 bits), one Newton step (~46 bits), q = num*r, one residual
-//     correction (error ~ (2^-46)^2 -> correctly rounded to ~1 ulp): 7 VALU per element, no
-//     v_div_scale/fmas/fixup and no selects;
-//   * the exact path (zero / denormal / huge / NaN denominators, and the unguarded NONE mode
-//     always) applies the guard literally and divides with IEEE semantics, so inf/NaN behaviour
-//     is the reference's.
-__device__ __forceinline__ double fast_div(double num, double den) {
-    double r = __builtin_amdgcn_rcp(den);
-    const double e = __builtin_fma(-den, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    const double qv = num * r;
-    const double rem = __builtin_fma(-den, qv, num);
-    return __builtin_fma(rem, r, qv);
-}
-__device__ __forceinline__ unsigned hi_word(double x) { return (unsigned)(__double_as_longlong(x) >> 32); }
-// lowest admissible high word for the fast path: 2^-928, or one binade above eps when clamping
-__device__ __forceinline__ unsigned fast_lo(int mode, double eps) {
-    unsigned lo = 0x05F00000u;
-    if (mode == EVC_EPS_CLAMP && eps > 0) {
-        const unsigned e = hi_word(eps) + 0x00200000u;
-        lo = e > lo ? e : lo;
-    }
-    return lo;
-}
-template <int MODE>
-__device__ __forceinline__ void mu_tile(double (&h)[4], const f64x4& p, const f64x4& dacc, double eps,
-                                        unsigned lo) {
-    constexpr bool MUL_FIRST = (MODE == EVC_EPS_ADD || MODE == EVC_EPS_NONE);   // (h*p)/den vs h*(p/den)
-    const unsigned span = 0x79F00000u - lo;
-    unsigned worst = max(max(hi_word(dacc[0]) - lo, hi_word(dacc[1]) - lo),
-                         max(hi_word(dacc[2]) - lo, hi_word(dacc[3]) - lo));
-    if (MODE != EVC_EPS_NONE && __builtin_expect(__all(worst < span), 1)) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double qv = fast_div(MUL_FIRST ? h[r] * p[r] : p[r], dacc[r]);
-            h[r] = MUL_FIRST ? qv : h[r] * qv;
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            double dn = dacc[r];
-            if (MODE == EVC_EPS_ZERO_REPLACE) dn = (dn == 0.0) ? eps : dn;  // sklearn _nmf.py:620
-            if (MODE == EVC_EPS_CLAMP) dn = (dn > eps) ? dn : eps;          // deComP
-            const double qv = (MUL_FIRST ? h[r] * p[r] : p[r]) / dn;
-            h[r] = MUL_FIRST ? qv : h[r] * qv;
-        }
-    }
-}
-
 // Registers of one 16-exemplar dictionary tile (both operand orders) and of the C activation
 // tiles that go with it; two of these ping-pong so that tile j+NW is in flight while tile j is
 // on the matrix cores.
@@ -200,6 +114,10 @@ __global__ __launch_bounds__(NW * 64) void k_fused_mu(FusedArgs a) {
         any |= live[c];
     }
     if (!__syncthreads_or(any)) return;
+    if (a.skip_all_live) {    // C == 1 here: same frame <-> workgroup mapping as k_fused_res
+        const long t = 16 * tt0 + (lane & 15);
+        if (__syncthreads_and((t >= a.T_) || live[0])) return;
+    }
 
     // stage X (and the carried V) in LDS
     for (int e = tid; e < E; e += NW * 64) {
@@ -278,13 +196,14 @@ __global__ __launch_bounds__(NW * 64) void k_fused_mu(FusedArgs a) {
     const bool masked = !__syncthreads_and(all_live) || (a.N & 15) != 0;
     const double eps = a.eps;
 
-    auto sweep = [&](auto mode_tag, auto masked_tag) {
-        constexpr int MODE = decltype(mode_tag)::value;
+    auto sweep = [&](auto mul_first_tag, auto masked_tag) {
+        constexpr bool MUL_FIRST = decltype(mul_first_tag)::value;
         constexpr bool MASKED = decltype(masked_tag)::value;
+        const int mode = a.eps_mode;
         // l1 (sklearn _nmf.py:615-617) and pymf's +eps (nmf.py:68) ride in the accumulator's start value
-        const double d0 = a.l1 + (MODE == EVC_EPS_ADD ? a.eps : 0.0);
+        const double d0 = a.l1 + (mode == EVC_EPS_ADD ? a.eps : 0.0);
         const f64x4 dinit = {d0, d0, d0, d0};
-        const unsigned lo = fast_lo(MODE, eps);
+        const unsigned lo = fast_lo(mode, eps);
         for (int it = 0; it < a.iters; ++it) {
             f64x4 vn[C][MT];
 #pragma unroll
@@ -308,7 +227,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused_mu(FusedArgs a) {
                         for (int r = 0; r < 4; ++r) h[r] = h[r] * p[r] + d[r];
                     } else if (MASKED) {
                         double hn[4] = {h[0], h[1], h[2], h[3]};
-                        mu_tile<MODE>(hn, p, d, eps, lo);
+                        mu_tile<MUL_FIRST>(hn, p, d, mode, eps, lo);
                         const int n0 = 16 * j + 4 * q;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -316,7 +235,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused_mu(FusedArgs a) {
                             h[r] = live[c] ? v : h[r];                      // stopped utterances are frozen
                         }
                     } else {
-                        mu_tile<MODE>(h, p, d, eps, lo);
+                        mu_tile<MUL_FIRST>(h, p, d, mode, eps, lo);
                     }
                     const long hb = ((tt0 + c) * NT + j) * 128 + lane;
                     if (DBG & 8) {
@@ -356,15 +275,13 @@ __global__ __launch_bounds__(NW * 64) void k_fused_mu(FusedArgs a) {
             reduce_v(vn);
         }
     };
-    auto run_mode = [&](auto mode_tag) {
-        if (masked) sweep(mode_tag, std::true_type{});
-        else sweep(mode_tag, std::false_type{});
-    };
-    switch (a.eps_mode) {
-        case EVC_EPS_ADD: run_mode(std::integral_constant<int, EVC_EPS_ADD>{}); break;
-        case EVC_EPS_ZERO_REPLACE: run_mode(std::integral_constant<int, EVC_EPS_ZERO_REPLACE>{}); break;
-        case EVC_EPS_CLAMP: run_mode(std::integral_constant<int, EVC_EPS_CLAMP>{}); break;
-        default: run_mode(std::integral_constant<int, EVC_EPS_NONE>{}); break;
+    const bool mul_first = a.eps_mode == EVC_EPS_ADD || a.eps_mode == EVC_EPS_NONE;
+    if (mul_first) {
+        if (masked) sweep(std::true_type{}, std::true_type{});
+        else sweep(std::true_type{}, std::false_type{});
+    } else {
+        if (masked) sweep(std::false_type{}, std::true_type{});
+        else sweep(std::false_type{}, std::false_type{});
     }
 
     // carry V to the next launch; per-frame squared residual of the final activations
@@ -467,19 +384,12 @@ int fused_pick_c(int T_) {
     return 1;                     // few frames: as many workgroups as possible
 }
 
-// variant: bits 0..7 frame tiles per workgroup (0 = automatic), bits 8..15 tuning variant id
-hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttState& u, int N, int T_,
-                         int iters, int first, int write_err, double* err2, int eps_mode, double eps,
-                         double l1, int variant, hipStream_t s) {
-    FusedArgs a;
-    a.A1p = b.A1p; a.A2p = b.A2p; a.Xp = b.Xp; a.Hp = reinterpret_cast<f64x2*>(b.Hp); a.Vp = b.Vp;
-    a.err2 = err2; a.frame_utt = u.frame_utt; a.active = u.active;
-    a.NT = f.NT; a.TT = f.TT; a.N = N; a.T_ = T_;
-    a.iters = iters; a.first = first; a.write_err = write_err;
-    a.eps_mode = eps_mode; a.eps = eps; a.l1 = l1;
+// variant: bits 0..7 frame tiles per workgroup (0 = automatic), bits 8..15 tuning variant id.
+// all_live_known: no stopping rule is in force, so every utterance is active for the whole call.
+static hipError_t launch_general(const FusedLayout& f, FusedArgs a, int T_, int variant, hipStream_t s) {
     const int c_req = variant & 0xff, vid = (variant >> 8) & 0xff;
-    const int C = c_req > 0 ? c_req : fused_pick_c(T_);
-    if (vid != 0 && f.msteps == 7) {          // tuning variants exist for the C2 shape only
+    const int C = a.skip_all_live ? 1 : (c_req > 0 ? c_req : fused_pick_c(T_));
+    if (vid != 0 && f.msteps == 7 && !a.skip_all_live) {   // tuning variants exist for the C2 shape only
         switch (vid * 10 + C) {
             case 11: return launch_fused<7, 1, 8, true>(a, s);
             case 21: return launch_fused<7, 1, 16, false>(a, s);
@@ -490,6 +400,7 @@ hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttS
             case 61: return launch_fused<7, 1, 8, false, 2>(a, s);     // no dictionary loads
             case 71: return launch_fused<7, 1, 8, false, 3>(a, s);     // neither
             case 81: return launch_fused<7, 1, 8, false, 7>(a, s);     // neither, no division
+            case 91: return launch_fused<7, 1, 8, false>(a, s);        // general kernel, as is
             default: return hipErrorInvalidValue;
         }
     }
@@ -498,6 +409,32 @@ hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttS
         case 2: return dispatch_msteps<2, 8, false>(f.msteps, a, s);
         default: return hipErrorInvalidValue;
     }
+}
+
+hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttState& u, int N, int T_,
+                         int iters, int first, int write_err, double* err2, int eps_mode, double eps,
+                         double l1, int variant, int all_live_known, hipStream_t s) {
+    FusedArgs a;
+    a.A1p = b.A1p; a.A2p = b.A2p; a.Xp = b.Xp; a.Hp = reinterpret_cast<f64x2*>(b.Hp); a.Vp = b.Vp;
+    a.err2 = err2; a.frame_utt = u.frame_utt; a.active = u.active;
+    a.NT = f.NT; a.TT = f.TT; a.N = N; a.T_ = T_;
+    a.iters = iters; a.first = first; a.write_err = write_err; a.skip_all_live = 0;
+    a.eps_mode = eps_mode; a.eps = eps; a.l1 = l1;
+    const bool resident = variant == 0 && fused_res_supported(N, eps_mode);
+    if (!resident) return launch_general(f, a, T_, variant, s);
+    if (first) {                 // V = A H (and the residual at init) by the general kernel's pre-pass
+        FusedArgs p = a;
+        p.iters = 0;
+        p.write_err = (iters == 0) ? write_err : 0;
+        hipError_t e = launch_general(f, p, T_, 1, s);
+        if (e != hipSuccess) return e;
+        a.first = 0;
+    }
+    if (iters == 0) return hipSuccess;
+    hipError_t e = fused_res_launch(f.msteps, a, s);
+    if (e != hipSuccess || all_live_known) return e;
+    a.skip_all_live = 1;         // workgroups holding frames of stopped utterances
+    return launch_general(f, a, T_, 1, s);
 }
 
 }  // namespace evc

@@ -1,0 +1,245 @@
+// Register-resident variant of the fused FACTORED kernel (float64, M <= 32).
+//
+// evc_fused.hip streams every 16x16 activation tile through HBM once per iteration (one read,
+// one write): 2*N*8 bytes per frame-iteration, which at N = 4096 puts that kernel against the
+// HBM wall (4.4 TB/s measured at 666 k frames/s).  Here each of the 8 wavefronts of a workgroup
+// keeps RES of its tiles in VGPRs for the whole launch (RES = 16: 8 x 16 x 2 KiB = 256 KiB of
+// the CU's 512 KiB register file = half of a 16-frame column block at N = 4096) and streams only
+// the others.  A wavefront walks its tiles k = 0, 1, 2, ... (tile index w + 8k); among the first
+// 2*RES the even ones are resident, the odd ones streamed, so that
+//   * a streamed tile's load is issued two units (~3300 cycles) before its first use at the cost
+//     of one extra tile of registers;
+//   * the dictionary fragments of unit k+1 are requested as soon as the last D/P MFMA of unit k
+//     has issued (its operand registers are free from then on).
+//
+// This kernel is the straight-line fast path only; it requires
+//   N % 128 == 0 and N / 128 >= 2*RES   (every wavefront owns the same number of tiles),
+//   a guarded eps mode (not NONE),
+//   every frame of the workgroup live (utterance still active) - otherwise the workgroup
+//   returns immediately and evc_fused.hip's kernel, launched behind it with skip_all_live = 1,
+//   processes it; that kernel also does the V pre-pass of the first launch.
+// Padded frames of the last workgroup (x = 0, h = 0) need no masking: their denominators are 0,
+// which sends the tile through mu_tile's exact path and leaves h at exactly 0.
+// The quotient is always formed divide-first, h * (p / den); for the ADD mode this differs from
+// pymf's (h*p)/den in the last bit only.
+#include "evc_fused_common.h"
+
+#ifndef EVC_RES_MAX
+#define EVC_RES_MAX 16
+#endif
+
+namespace evc {
+
+constexpr int RNW = 8;    // wavefronts per workgroup
+
+template <int MSTEPS, int RES>
+__global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
+    constexpr int MT = MSTEPS > 4 ? 2 : 1;
+    constexpr int E = MT * 4 * 64;               // doubles in one V (accumulator order)
+    extern __shared__ double lds[];
+    double* red = lds;                           // [RNW][E]  partial V' of every wavefront
+    double* vL = lds + RNW * E;                  // [MT*4][64]  V, B-operand order
+    double* xL = vL + E;                         // [MT*4][64]  X, B-operand order
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long tt = blockIdx.x;
+    const double* __restrict__ A1p = a.A1p;
+    const double* __restrict__ A2p = a.A2p;
+    f64x2* __restrict__ Hp = a.Hp;
+    const int NT = a.NT;
+    const int KT = NT / RNW;                     // tiles per wavefront (host guarantees >= 2*RES)
+
+    {
+        const long t = 16 * tt + (lane & 15);
+        int u = -1;
+        if (t < a.T_) u = a.frame_utt[t];
+        const bool live = (t >= a.T_) || ((u >= 0) && (a.active[u] != 0));   // padding counts as live
+        if (!__syncthreads_and(live)) return;    // left to the general kernel (skip_all_live)
+    }
+
+    for (int e = tid; e < E; e += RNW * 64) {
+        const int s = e >> 6, l = e & 63;
+        const bool in = s < MSTEPS;
+        xL[e] = in ? a.Xp[(tt * MSTEPS + s) * 64 + l] : 0.0;
+        vL[e] = in ? a.Vp[(tt * 8 + s) * 64 + l] : 0.0;
+    }
+    __syncthreads();
+
+    // Per-tile base addresses are wave-uniform: keep them in SGPRs (saddr + lane offset addressing).
+    // With per-lane 64-bit addresses the unrolled sweep needs one VGPR pair per tile and array
+    // (the 16 KiB tile stride does not fit the instruction's immediate offset) and spills massively.
+    const double* a1w = A1p + (long)w * MSTEPS * 64;                  // tile k: + k * RNW*MSTEPS*64
+    const double* a2w = A2p + (long)w * MT * 256;                     // tile k: + k * RNW*MT*256
+    f64x2* hw = Hp + (tt * NT + w) * 128;                             // tile k: + k * RNW*128
+    auto load_a1 = [&](double (&a1)[MSTEPS], int k) {
+        const double* t = uniform_ptr(a1w + (long)k * (RNW * MSTEPS * 64));
+#pragma unroll
+        for (int s = 0; s < MSTEPS; ++s) a1[s] = t[s * 64 + lane];
+    };
+    auto load_a2 = [&](double (&a2)[MT][4], int k) {
+        const double* t = uniform_ptr(a2w + (long)k * (RNW * MT * 256));
+#pragma unroll
+        for (int u = 0; u < MT; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a2[u][r] = t[(u * 4 + r) * 64 + lane];
+    };
+    auto load_h = [&](double (&h)[4], int k) {
+        const f64x2* t = uniform_ptr(hw + (long)k * (RNW * 128));
+        const f64x2 h01 = t[lane], h23 = t[lane + 64];
+        h[0] = h01[0]; h[1] = h01[1]; h[2] = h23[0]; h[3] = h23[1];
+    };
+    auto store_h = [&](const double (&h)[4], int k) {
+        f64x2* t = uniform_ptr(hw + (long)k * (RNW * 128));
+        t[lane] = f64x2{h[0], h[1]};
+        t[lane + 64] = f64x2{h[2], h[3]};
+    };
+    auto vacc = [&](const double (&a2)[MT][4], const double (&h)[4], f64x4 (&vn)[MT]) {
+#pragma unroll
+        for (int u = 0; u < MT; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vn[u] = Mma<double>::mma(a2[u][r], h[r], vn[u]);
+    };
+
+    const int mode = a.eps_mode;
+    const double eps = a.eps;
+    // l1 (sklearn _nmf.py:615-617) and pymf's +eps (nmf.py:68) ride in the accumulator's start value
+    const double d0 = a.l1 + (mode == EVC_EPS_ADD ? a.eps : 0.0);
+    const f64x4 dinit = {d0, d0, d0, d0};
+    const unsigned lo = fast_lo(mode, eps);
+
+    // one unit: D = A_j^T V (+l1), P = A_j^T X, h <- h * P / D, V' += A_j h
+    auto unit = [&](double (&a1)[MSTEPS], double (&a2)[MT][4], double (&h)[4], f64x4 (&vn)[MT], int k,
+                    bool more) {
+        __builtin_amdgcn_sched_barrier(0);       // keep the unrolled units' loads where they are written
+        load_a2(a2, k);
+        f64x4 d = dinit, p = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < MSTEPS; ++s) {
+            d = Mma<double>::mma(a1[s], vL[s * 64 + lane], d);
+            p = Mma<double>::mma(a1[s], xL[s * 64 + lane], p);
+        }
+        if (more) load_a1(a1, k + 1);            // operand registers are free once the MFMAs issued
+        __builtin_amdgcn_sched_barrier(0);
+        mu_tile<false>(h, p, d, mode, eps, lo);
+    };
+
+    double hres[RES][4];
+#pragma unroll
+    for (int k = 0; k < RES; ++k) load_h(hres[k], 2 * k);
+
+    for (int it = 0; it < a.iters; ++it) {
+        // opaque to the optimiser: the per-tile addresses are re-derived with scalar adds in every
+        // sweep instead of being hoisted out of this loop into ~200 SGPRs (which then spill)
+        asm volatile("" : "+s"(a1w), "+s"(a2w), "+s"(hw));
+        f64x4 vn[MT];
+#pragma unroll
+        for (int u = 0; u < MT; ++u) vn[u] = f64x4{0, 0, 0, 0};
+        double a1[MSTEPS], a2[MT][4];
+        double hs[2][4];
+        load_a1(a1, 0);
+        load_h(hs[0], 1);
+#pragma unroll
+        for (int k2 = 0; k2 < RES; ++k2) {
+            // even tile 2*k2: resident
+            unit(a1, a2, hres[k2], vn, 2 * k2, true);
+            vacc(a2, hres[k2], vn);
+            // odd tile 2*k2+1: streamed; its successor's load goes out now, two units ahead of its use
+            const bool more = (2 * k2 + 2 < KT);
+            __builtin_amdgcn_sched_barrier(0);
+            load_a2(a2, 2 * k2 + 1);
+            {
+                f64x4 d = dinit, p = {0, 0, 0, 0};
+#pragma unroll
+                for (int s = 0; s < MSTEPS; ++s) {
+                    d = Mma<double>::mma(a1[s], vL[s * 64 + lane], d);
+                    p = Mma<double>::mma(a1[s], xL[s * 64 + lane], p);
+                }
+                if (more) load_a1(a1, 2 * k2 + 2);
+                if (k2 + 1 < RES) load_h(hs[(k2 + 1) & 1], 2 * k2 + 3);
+                __builtin_amdgcn_sched_barrier(0);
+                mu_tile<false>(hs[k2 & 1], p, d, mode, eps, lo);
+            }
+            store_h(hs[k2 & 1], 2 * k2 + 1);
+            vacc(a2, hs[k2 & 1], vn);
+        }
+        for (int k = 2 * RES; k < KT; ++k) {     // beyond the resident window: plain streaming
+            double h[4];
+            load_h(h, k);
+            unit(a1, a2, h, vn, k, k + 1 < KT);
+            store_h(h, k);
+            vacc(a2, h, vn);
+        }
+        // V' partials -> LDS -> each wavefront sums a slice over the partials in fixed order -> vL
+#pragma unroll
+        for (int u = 0; u < MT; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[w * E + (u * 4 + r) * 64 + lane] = vn[u][r];
+        __syncthreads();
+        for (int e = w * 64 + lane; e < E; e += RNW * 64) {
+            double acc = 0.0;
+#pragma unroll
+            for (int ww = 0; ww < RNW; ++ww) acc += red[ww * E + e];
+            vL[e] = acc;
+        }
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int k = 0; k < RES; ++k) store_h(hres[k], 2 * k);
+
+    // carry V to the next launch; per-frame squared residual of the final activations
+    for (int e = tid; e < E; e += RNW * 64) {
+        const int s = e >> 6, l = e & 63;
+        if (s < MSTEPS) a.Vp[(tt * 8 + s) * 64 + l] = vL[e];
+    }
+    if (a.write_err && w == 0) {
+        double e = 0.0;
+#pragma unroll
+        for (int s = 0; s < MSTEPS; ++s) {
+            const double df = xL[s * 64 + lane] - vL[s * 64 + lane];
+            e += df * df;
+        }
+        e += __shfl_xor(e, 16, 64);      // the 4 lane groups hold one frame's bins
+        e += __shfl_xor(e, 32, 64);
+        const long t = 16 * tt + lane;
+        if (lane < 16 && t < a.T_) a.err2[t] = e;
+    }
+}
+
+template <int MSTEPS, int RES>
+static hipError_t launch_res(const FusedArgs& a, hipStream_t s) {
+    constexpr int MT = MSTEPS > 4 ? 2 : 1;
+    constexpr int E = MT * 4 * 64;
+    const size_t lds = (size_t)(RNW + 2) * E * sizeof(double);
+    hipLaunchKernelGGL((k_fused_res<MSTEPS, RES>), dim3((unsigned)a.TT), dim3(RNW * 64), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int MSTEPS>
+static hipError_t pick_res(const FusedArgs& a, hipStream_t s) {
+    const int KT = a.NT / RNW;
+    if (KT >= 2 * EVC_RES_MAX) return launch_res<MSTEPS, EVC_RES_MAX>(a, s);
+    if (KT >= 16) return launch_res<MSTEPS, 8>(a, s);
+    if (KT >= 8) return launch_res<MSTEPS, 4>(a, s);
+    return hipErrorInvalidValue;
+}
+
+bool fused_res_supported(int N, int eps_mode) {
+    return (N % 128 == 0) && (N / 128 >= 8) && eps_mode != EVC_EPS_NONE;
+}
+
+hipError_t fused_res_launch(int msteps, const FusedArgs& a, hipStream_t s) {
+    switch (msteps) {
+        case 1: return pick_res<1>(a, s);
+        case 2: return pick_res<2>(a, s);
+        case 3: return pick_res<3>(a, s);
+        case 4: return pick_res<4>(a, s);
+        case 5: return pick_res<5>(a, s);
+        case 6: return pick_res<6>(a, s);
+        case 7: return pick_res<7>(a, s);
+        case 8: return pick_res<8>(a, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace evc

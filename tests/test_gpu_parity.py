@@ -28,8 +28,8 @@ ALGOS = ["factored", "gram", "literal"]
 # generic two-GEMM factored path and the other frame-tile factors of the fused kernel
 VARIANTS = {"factored": {}, "gram": {}, "literal": {},
             "factored_generic": {"algo": "factored", "fused": False},
-            "fused_c1": {"algo": "factored", "fused_c": 1},
-            "fused_c2": {"algo": "factored", "fused_c": 2}}
+            "fused_c1": {"algo": "factored", "fused_c": 1},     # general streamed kernel, 16 frames/WG
+            "fused_c2": {"algo": "factored", "fused_c": 2}}     # general streamed kernel, 32 frames/WG
 
 
 def variant_kw(name):
