@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libevc_hip.so")
+# EVC_LIB overrides the library path (A/B builds during kernel tuning)
+LIB_PATH = os.environ.get("EVC_LIB") or os.path.join(_HERE, "libevc_hip.so")
 
 F64, F32 = 0, 1
 FRAME_MAJOR, BIN_MAJOR = 0, 1

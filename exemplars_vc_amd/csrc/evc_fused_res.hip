@@ -65,33 +65,38 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
     }
     __syncthreads();
 
-    // Per-tile base addresses are wave-uniform: keep them in SGPRs (saddr + lane offset addressing).
-    // With per-lane 64-bit addresses the unrolled sweep needs one VGPR pair per tile and array
-    // (the 16 KiB tile stride does not fit the instruction's immediate offset) and spills massively.
-    const double* a1w = A1p + (long)w * MSTEPS * 64;                  // tile k: + k * RNW*MSTEPS*64
-    const double* a2w = A2p + (long)w * MT * 256;                     // tile k: + k * RNW*MT*256
-    f64x2* hw = Hp + (tt * NT + w) * 128;                             // tile k: + k * RNW*128
+    // Per-tile base addresses are wave-uniform (SGPR base + unsigned per-lane offset -> the
+    // global_load saddr form).  With per-lane 64-bit addresses the unrolled sweep needs one VGPR
+    // pair per tile and array (the 16 KiB tile stride does not fit the instruction's immediate
+    // offset) and spills massively.  `sw` is an opaque zero added to the offsets once per sweep so
+    // that the ~100 tile addresses are re-derived with scalar adds instead of being hoisted out of
+    // the iteration loop into SGPRs that then spill.
+    const unsigned ul = (unsigned)lane;
+    long sw = 0;
+    const long a1w = (long)w * MSTEPS * 64;                           // tile k: + k * RNW*MSTEPS*64
+    const long a2w = (long)w * MT * 256;                              // tile k: + k * RNW*MT*256
+    const long hw = (tt * NT + w) * 128;                              // tile k: + k * RNW*128
     auto load_a1 = [&](double (&a1)[MSTEPS], int k) {
-        const double* t = uniform_ptr(a1w + (long)k * (RNW * MSTEPS * 64));
+        const double* t = A1p + (a1w + sw + (long)k * (RNW * MSTEPS * 64));
 #pragma unroll
-        for (int s = 0; s < MSTEPS; ++s) a1[s] = t[s * 64 + lane];
+        for (int s = 0; s < MSTEPS; ++s) a1[s] = t[s * 64 + ul];
     };
     auto load_a2 = [&](double (&a2)[MT][4], int k) {
-        const double* t = uniform_ptr(a2w + (long)k * (RNW * MT * 256));
+        const double* t = A2p + (a2w + sw + (long)k * (RNW * MT * 256));
 #pragma unroll
         for (int u = 0; u < MT; ++u)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) a2[u][r] = t[(u * 4 + r) * 64 + lane];
+            for (int r = 0; r < 4; ++r) a2[u][r] = t[(u * 4 + r) * 64 + ul];
     };
     auto load_h = [&](double (&h)[4], int k) {
-        const f64x2* t = uniform_ptr(hw + (long)k * (RNW * 128));
-        const f64x2 h01 = t[lane], h23 = t[lane + 64];
+        const f64x2* t = Hp + (hw + sw + (long)k * (RNW * 128));
+        const f64x2 h01 = t[ul], h23 = t[ul + 64];
         h[0] = h01[0]; h[1] = h01[1]; h[2] = h23[0]; h[3] = h23[1];
     };
     auto store_h = [&](const double (&h)[4], int k) {
-        f64x2* t = uniform_ptr(hw + (long)k * (RNW * 128));
-        t[lane] = f64x2{h[0], h[1]};
-        t[lane + 64] = f64x2{h[2], h[3]};
+        f64x2* t = Hp + (hw + sw + (long)k * (RNW * 128));
+        t[ul] = f64x2{h[0], h[1]};
+        t[ul + 64] = f64x2{h[2], h[3]};
     };
     auto vacc = [&](const double (&a2)[MT][4], const double (&h)[4], f64x4 (&vn)[MT]) {
 #pragma unroll
@@ -127,17 +132,19 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
 #pragma unroll
     for (int k = 0; k < RES; ++k) load_h(hres[k], 2 * k);
 
+    double a1[MSTEPS], a2[MT][4];
+    double hs[2][4];
     for (int it = 0; it < a.iters; ++it) {
         // opaque to the optimiser: the per-tile addresses are re-derived with scalar adds in every
         // sweep instead of being hoisted out of this loop into ~200 SGPRs (which then spill)
-        asm volatile("" : "+s"(a1w), "+s"(a2w), "+s"(hw));
+        asm volatile("" : "+s"(sw));
         f64x4 vn[MT];
 #pragma unroll
         for (int u = 0; u < MT; ++u) vn[u] = f64x4{0, 0, 0, 0};
-        double a1[MSTEPS], a2[MT][4];
-        double hs[2][4];
-        load_a1(a1, 0);
-        load_h(hs[0], 1);
+        if (it == 0) {
+            load_a1(a1, 0);
+            load_h(hs[0], 1);
+        }
 #pragma unroll
         for (int k2 = 0; k2 < RES; ++k2) {
             // even tile 2*k2: resident
@@ -168,6 +175,11 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
             unit(a1, a2, h, vn, k, k + 1 < KT);
             store_h(h, k);
             vacc(a2, h, vn);
+        }
+        // the next sweep's first operands do not depend on V': request them before the combine
+        if (it + 1 < a.iters) {
+            load_a1(a1, 0);
+            load_h(hs[0], 1);      // tile 1 was stored earlier in this sweep by this very wavefront
         }
         // V' partials -> LDS -> each wavefront sums a slice over the partials in fixed order -> vL
 #pragma unroll

@@ -1,0 +1,70 @@
+"""The C-ABI library: loads without a GPU, exports every symbol include/evc.h declares, and
+rejects bad arguments before touching the device.  No compute calls here (CPU container)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+def lib():
+    from exemplars_vc_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        from exemplars_vc_amd.csrc.build import build
+        build()
+    return _lib, _lib.lib()
+
+
+def test_exports_every_declared_symbol():
+    _lib, L = lib()
+    hdr = open(os.path.join(ROOT, "include", "evc.h")).read()
+    declared = set(re.findall(r"\b(evc_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for sym in declared:
+        assert hasattr(L, sym), sym
+    assert L.evc_version() == 100
+
+
+def test_struct_mirror_matches_header_fields():
+    _lib, _ = lib()
+    hdr = open(os.path.join(ROOT, "include", "evc.h")).read()
+    body = hdr[hdr.index("typedef struct evc_solve_opts {"):hdr.index("} evc_solve_opts;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"\b(?:int|double|void\*)\s+([a-z_0-9]+);", body)
+    assert fields == [f[0] for f in _lib.SolveOpts._fields_]
+
+
+def test_strerror_and_workspace_queries():
+    _lib, L = lib()
+    assert _lib.strerror(0) == "ok"
+    assert "argument" in _lib.strerror(-1) and "workspace" in _lib.strerror(-2)
+    small = L.evc_workspace_bytes(25, 512, 688, 1, _lib.F64, _lib.ALGO_FACTORED)
+    big = L.evc_workspace_bytes(25, 4096, 688, 1, _lib.F64, _lib.ALGO_FACTORED)
+    gram = L.evc_workspace_bytes(25, 4096, 688, 1, _lib.F64, _lib.ALGO_GRAM)
+    assert 0 < small < big < gram
+    assert L.evc_workspace_bytes(25, 4096, 688, 1, _lib.F32, _lib.ALGO_GRAM) < gram
+    assert L.evc_workspace_bytes(-1, 1, 1, 1, 0, 0) == 0 and L.evc_workspace_bytes(1, 1, 1, 1, 7, 0) == 0
+
+
+def test_bad_arguments_are_rejected_before_any_device_work():
+    _lib, L = lib()
+    o = _lib.SolveOpts()
+    o.struct_bytes = 4                     # wrong size
+    one = C.c_void_p(8)
+    args = lambda opts, **kw: L.evc_nmf_solve(one, 25, one, 25, one, 64, kw.get("M", 25), 64, kw.get("T", 10),
+                                              None, 1, C.byref(opts), one, 1 << 30, None, None, None)
+    assert args(o) == -1
+    o.struct_bytes = C.sizeof(_lib.SolveOpts)
+    o.iters = -1
+    assert args(o) == -1
+    o.iters = 5; o.eps_mode = 9
+    assert args(o) == -1
+    o.eps_mode = 0; o.stop_rule = _lib.STOP_SKLEARN; o.check_every = 0
+    assert args(o) == -1                   # a stopping rule needs residual evaluations
+    o.stop_rule = 0
+    assert args(o, M=0) == -1
+    assert args(o, T=0) == 0               # nothing to do is not an error
+    assert L.evc_synthesize(one, 1, one, 64, one, 25, 25, 64, 10, 0, 0, None) == -1   # ldb < Mb
+    assert L.evc_synthesize(one, 25, one, 64, one, 25, 25, 64, 0, 0, 0, None) == 0

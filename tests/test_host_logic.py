@@ -1,0 +1,98 @@
+"""Host-side behaviour that needs no GPU: argument validation of the drop-in surfaces, loud
+failure without a device, the utterance partitioner."""
+import numpy as np
+import pytest
+
+import exemplars_vc_amd as evc
+from exemplars_vc_amd.shard import partition_utterances
+
+
+def has_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+def test_no_cpu_fallback():
+    if has_gpu():
+        pytest.skip("device present")
+    A = np.ones((4, 8)); X = np.ones((4, 3))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        evc.solve_activations(A, X, iters=1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        evc.synthesize(A, np.ones((8, 3)))
+
+
+def test_product_package_does_not_import_the_oracle():
+    import sys
+    import importlib
+    for m in [k for k in sys.modules if k.startswith("oracle")]:
+        del sys.modules[m]
+    importlib.reload(evc)
+    assert not any(k.startswith("oracle") for k in sys.modules)
+    import os, glob
+    pkg = os.path.dirname(evc.__file__)
+    for f in glob.glob(os.path.join(pkg, "**", "*.py"), recursive=True):
+        assert "oracle" not in open(f).read().replace("the oracle", ""), f
+
+
+def test_factorize_validation_mirrors_sklearn():
+    from exemplars_vc_amd.compat.factorize import _factorize
+    X = np.ones((5, 4))
+    with pytest.raises(ValueError, match="Negative values"):
+        _factorize(X, -np.ones((3, 4)))
+    with pytest.raises(ValueError, match="full of zeros"):
+        _factorize(X, np.zeros((3, 4)))
+    with pytest.raises(ValueError, match="wrong second dimension"):
+        _factorize(X, np.ones((3, 5)))
+    with pytest.raises(TypeError, match="same dtype"):
+        _factorize(X, np.ones((3, 4), dtype=np.float32))
+    with pytest.raises(ValueError, match="2D"):
+        _factorize(np.ones(4), np.ones((3, 4)))
+
+
+def test_pymf_and_nmf_tool_surface_contracts():
+    from exemplars_vc_amd.compat.pymf import NMF as PNMF
+    from exemplars_vc_amd.compat.nmf_tool import NMF as TNMF
+    m = PNMF(np.ones((4, 6)), num_bases=3)
+    assert (m._data_dimension, m._num_samples, m._num_bases) == (4, 6, 3)
+    with pytest.raises(NotImplementedError):
+        m.factorize(niter=2)                       # compute_w=True is outside the path
+    with pytest.raises(AttributeError):
+        m.factorize(niter=2, compute_w=False)      # W not set
+    np.random.seed(3)
+    m._init_h()
+    np.random.seed(3)
+    assert np.array_equal(m.H, np.random.random((3, 6)) + 1e-4)   # pymf base.py:174-177
+    t = TNMF(max_iter=5, optimizer="pg")
+    with pytest.raises(NotImplementedError):
+        t.fit_transform(np.ones((4, 6)), 3, True, np.ones((4, 3)))
+    with pytest.raises(NotImplementedError):
+        TNMF(max_iter=5).fit_transform(np.ones((4, 6)), 3, False, 0)
+
+
+def test_solver_argument_errors_without_touching_the_device(monkeypatch):
+    import exemplars_vc_amd.solver as S
+    import torch
+
+    class Stop(Exception):
+        pass
+    # let validation run, stop right before any device work
+    monkeypatch.setattr(S, "require_device", lambda d=None: torch.device("cpu"))
+    with pytest.raises(ValueError, match="number of bins"):
+        S.solve_activations(np.ones((4, 8)), np.ones((5, 3)), iters=1)
+    with pytest.raises(ValueError, match="expected"):
+        S.solve_activations(np.ones((4, 8)), np.ones((4, 3)), np.ones((7, 3)), iters=1)
+    with pytest.raises(KeyError):
+        S.solve_activations(np.ones((4, 8)), np.ones((4, 3)), iters=1, eps_mode="bogus")
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 8])
+def test_partition_is_a_balanced_partition(n):
+    rng = np.random.default_rng(n)
+    lens = list(rng.integers(100, 1500, size=37))
+    parts = partition_utterances(lens, n)
+    assert sorted(i for p in parts for i in p) == list(range(37))
+    loads = [sum(lens[i] for i in p) for p in parts]
+    assert max(loads) - min(loads) <= max(lens)
+    assert partition_utterances(lens, n) == parts          # deterministic
+    assert partition_utterances([], n) == [[] for _ in range(n)]
