@@ -5,7 +5,8 @@ A "step" is one pass of the hot path over one batch of synthetic utterances alre
 resident in HBM: activation solve (K multiplicative updates against the fixed dictionary A,
 scikit-learn semantics as called by 04_align_n_nmf.py: constant init, zero->EPSILON guard,
 fixed K, no early stop) followed by the synthesis Y = B H.  Default workload is BASELINE.json
-configs[1] ("C2"): M=25 bins, N=4096 exemplars, K=100, float64, 96 utterances x 688 frames.
+configs[1] ("C2"): M=25 bins, N=4096 exemplars, K=100, float64, 192 utterances x 688 frames
+(the size of the reference's corpus: 162 utterances, BASELINE.md C4, rounded up).
 
   python bench.py [--gpus N --steps K --warmup W]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -94,7 +95,7 @@ def main():
     ap.add_argument("--bins", type=int, default=25)
     ap.add_argument("--exemplars", type=int, default=4096)
     ap.add_argument("--iters", type=int, default=100)
-    ap.add_argument("--utterances", type=int, default=96)
+    ap.add_argument("--utterances", type=int, default=192)
     ap.add_argument("--frames", type=int, default=688, help="frames per utterance")
     ap.add_argument("--algo", default="factored", choices=["factored", "gram", "literal"])
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
@@ -188,13 +189,13 @@ def main():
             "config": {"workload": f"C2 (BASELINE configs[1]): SF1->TF1-shaped dictionary, M={M} bins, "
                                    f"N={N} exemplars, K={K} MU iterations, {U} utterances x {Tu} frames "
                                    f"= {T} frames per GPU per step, solve + synthesis B*H",
-                       "algo": args.algo, "kernel": "k_fused_mu (persistent, 1 launch per step)" if fused
+                       "algo": args.algo, "kernel": "k_fused_res (persistent, register-resident, 1 launch per step)" if fused
                        else "k_gemm_nt(+mu epilogue), launches per iteration",
                        "frames_per_gpu": T, "parallelism": f"utterance shards x{world}"},
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak, "traffic": None,
-                "kernel": "iteration loop (k_fused_mu)" if fused else "iteration loop (k_gemm_nt family)",
+                "kernel": "iteration loop (k_fused_res)" if fused else "iteration loop (k_gemm_nt family)",
                 "launch_ms": 1e3 * loop_s,
                 "algorithmic_flops_per_launch": fl_loop,
                 "note": "achieved = algorithmic flops of the executed algebra (K*(4MN+3N) per frame "
