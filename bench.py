@@ -139,17 +139,17 @@ def main():
     A, B, X = A.to(tdt), B.to(tdt), X.to(tdt).contiguous()
     offs = np.arange(U + 1, dtype=np.int32) * Tu
     H = torch.empty(T, N, dtype=tdt, device=dev)
+    Yout = torch.empty(T, M, dtype=tdt, device=dev)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record(); ev1.record()          # force creation of the underlying hipEvent_t
     torch.cuda.synchronize()
     loop_ms = []
 
     def step(timed):
-        evc.solve_activations(A, X, layout="frame_major", iters=K, eps_mode="zero_replace",
-                              init="sklearn", algo=args.algo, utt_offsets=offs, out=H,
-                              fused=not args.no_fused, fused_c=args.fused_c,
-                              loop_events=(ev0, ev1))
-        Y = evc.synthesize(B, H, layout="frame_major")
+        # factorize() + convert(): H (T x N) and Y = H B (T x Mb) both delivered in HBM
+        _, Y = evc.convert(A, X, B, layout="frame_major", iters=K, eps_mode="zero_replace",
+                           init="sklearn", algo=args.algo, utt_offsets=offs, out=H, out_y=Yout,
+                           fused=not args.no_fused, fused_c=args.fused_c, loop_events=(ev0, ev1))
         if timed:
             ev1.synchronize()
             loop_ms.append(ev0.elapsed_time(ev1))
@@ -209,10 +209,9 @@ def main():
             res["speedup_vs_cpu"] = value / cpu["value"]
             # parity of the GPU path on the very sample the CPU leg timed
             Xs = np.ascontiguousarray(p["X"].T)
-            Hg = evc.solve_activations(np.ascontiguousarray(p["A"].T), Xs, layout="frame_major", iters=K,
-                                       eps_mode="zero_replace", init="sklearn", algo=args.algo,
-                                       dtype=args.dtype, fused=not args.no_fused)
-            Yg = evc.synthesize(np.ascontiguousarray(p["B"].T).astype(Hg.dtype), Hg, layout="frame_major")
+            Hg, Yg = evc.convert(np.ascontiguousarray(p["A"].T), Xs, np.ascontiguousarray(p["B"].T),
+                                 layout="frame_major", iters=K, eps_mode="zero_replace", init="sklearn",
+                                 algo=args.algo, dtype=args.dtype, fused=not args.no_fused)
             nz = act_cpu != 0
             res["parity"] = {
                 "H_max_rel_err": float(np.max(np.abs(Hg[nz] - act_cpu[nz]) / act_cpu[nz])),

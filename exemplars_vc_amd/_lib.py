@@ -21,7 +21,7 @@ STOP_NONE, STOP_SKLEARN, STOP_PYMF = 0, 1, 2
 
 # every symbol include/evc.h declares; tests check that the library exports all of them
 SYMBOLS = ("evc_version", "evc_strerror", "evc_device_count", "evc_workspace_bytes",
-           "evc_nmf_solve", "evc_synthesize", "evc_residual")
+           "evc_nmf_solve", "evc_nmf_convert", "evc_synthesize", "evc_residual")
 
 
 class SolveOpts(C.Structure):
@@ -63,7 +63,7 @@ def lib():
     L.evc_strerror.argtypes = [C.c_int]
     L.evc_device_count.restype = C.c_int
     L.evc_workspace_bytes.restype = C.c_size_t
-    L.evc_workspace_bytes.argtypes = [C.c_int] * 6
+    L.evc_workspace_bytes.argtypes = [C.c_int] * 7
     L.evc_nmf_solve.restype = C.c_int
     L.evc_nmf_solve.argtypes = [
         C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,      # A, X, H
@@ -73,6 +73,14 @@ def lib():
         C.c_void_p, C.c_size_t,                                             # workspace
         C.POINTER(C.c_int), C.POINTER(C.c_double),                          # n_iter_out, err_out
         C.c_void_p,                                                         # stream
+    ]
+    L.evc_nmf_convert.restype = C.c_int
+    L.evc_nmf_convert.argtypes = [
+        C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,      # A, X, B
+        C.c_void_p, C.c_int, C.c_void_p, C.c_int,                           # H, Y
+        C.c_int, C.c_int, C.c_int, C.c_int,                                 # M, Mb, N, T
+        C.POINTER(C.c_int), C.c_int, C.POINTER(SolveOpts),
+        C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_void_p,
     ]
     L.evc_synthesize.restype = C.c_int
     L.evc_synthesize.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,

@@ -23,13 +23,13 @@ struct Carver {
 };
 
 struct Dims {
-    int M, N, T_, n_utt;
+    int M, N, T_, n_utt, Mb;
     int Mk, Mj, Np, Tp;
 };
 
-Dims make_dims(int M, int N, int T_, int n_utt) {
+Dims make_dims(int M, int N, int T_, int n_utt, int Mb = 0) {
     Dims d;
-    d.M = M; d.N = N; d.T_ = T_; d.n_utt = n_utt;
+    d.M = M; d.N = N; d.T_ = T_; d.n_utt = n_utt; d.Mb = Mb;
     d.Mk = round_up(M, 16);
     d.Mj = round_up(M, 64);
     d.Np = round_up(N, 128);
@@ -43,7 +43,11 @@ template <typename T> struct Workspace {
     UttState u;
     FusedLayout fl;
     FusedBuffers fb;
-    bool fused;
+    // synthesis from the packed activations (fused path, Mb <= 32)
+    FusedLayout flB;
+    T* Bt;
+    double *B1p, *B2p, *Yp;
+    bool fused, packed_synth;
     size_t bytes;
 };
 
@@ -58,7 +62,11 @@ Workspace<T> carve(void* base, const Dims& d, int algo, int n_slots, bool fused)
     w.At = c.take<T>((size_t)d.Np * d.Mk);
     w.Am = c.take<T>((size_t)d.Mj * d.Np);
     w.Xt = c.take<T>((size_t)d.Tp * d.Mk);
-    w.H0 = c.take<T>((size_t)d.Tp * d.Np);
+    w.packed_synth = fused && d.Mb >= 1 && d.Mb <= 32;
+    // the fused path keeps the activations in the packed layout only; a frames-as-rows copy is
+    // needed by the generic path, and by a synthesis that cannot run from the packed tiles
+    const bool need_h0 = !fused || (d.Mb > 32);
+    w.H0 = need_h0 ? c.take<T>((size_t)d.Tp * d.Np) : nullptr;
     w.Pt = fused ? nullptr : c.take<T>((size_t)d.Tp * d.Np);
     w.Vt = fused ? nullptr : c.take<T>((size_t)d.Tp * d.Mj);
     w.fl = FusedLayout{};
@@ -70,6 +78,15 @@ Workspace<T> carve(void* base, const Dims& d, int algo, int n_slots, bool fused)
         w.fb.Xp = c.take<double>(w.fl.xp);
         w.fb.Hp = c.take<double>(w.fl.hp);
         w.fb.Vp = c.take<double>(w.fl.vp);
+    }
+    w.flB = FusedLayout{};
+    w.Bt = nullptr; w.B1p = w.B2p = w.Yp = nullptr;
+    if (w.packed_synth) {
+        w.flB = fused_layout(d.Mb, d.N, d.T_);
+        w.Bt = c.take<T>((size_t)d.Np * 32);
+        w.B1p = c.take<double>(w.flB.a1);
+        w.B2p = c.take<double>(w.flB.a2);
+        w.Yp = c.take<double>(w.flB.vp);
     }
     w.H1 = gram ? c.take<T>((size_t)d.Tp * d.Np) : nullptr;
     w.G = gram ? c.take<T>((size_t)d.Np * d.Np) : nullptr;
@@ -101,20 +118,32 @@ bool use_fused(int M, int N, int T_, int dtype, int algo) {
 // so the trace region is sized for MAX_SLOTS checks and evc_nmf_solve rejects more.
 constexpr int MAX_SLOTS = 4097;
 
-// export the activations to the caller's layout and hand back the per-utterance results
-template <typename T>
-int finish(const Workspace<T>& w, const Dims& d, const evc_solve_opts& o, const T* Hc, T* H, int ldh,
-           int n_utt, int n_slots, int* n_iter_out, double* err_out, hipStream_t s) {
-    const bool fm = (o.layout == EVC_FRAME_MAJOR);
-    HIP_TRY(copy2d<T>(Hc, d.Np, d.T_, d.N, 0, H, ldh, d.T_, d.N, fm ? 0 : 1, s));
+struct SynthArgs {          // optional Y = B H appended to a solve (evc_nmf_convert)
+    const void* B; int ldb; void* Y; int ldy; int Mb;
+};
+
+// hand back the per-utterance results
+int copy_back(const UttState& u, int n_utt, int n_slots, int* n_iter_out, double* err_out, hipStream_t s) {
     if (n_iter_out || err_out) {
         if (n_iter_out)
-            HIP_TRY(hipMemcpyAsync(n_iter_out, w.u.n_iter, sizeof(int) * n_utt, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipMemcpyAsync(n_iter_out, u.n_iter, sizeof(int) * n_utt, hipMemcpyDeviceToHost, s));
         if (err_out)
-            HIP_TRY(hipMemcpyAsync(err_out, w.u.trace, sizeof(double) * (size_t)n_utt * n_slots,
+            HIP_TRY(hipMemcpyAsync(err_out, u.trace, sizeof(double) * (size_t)n_utt * n_slots,
                                    hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
+    return ST_OK;
+}
+
+// Y = B H on frames-as-rows activations Hc (row stride ldc) and the caller's B / Y
+template <typename T>
+int synth_rows(const T* Hc, long ldc, const SynthArgs& y, int N, int T_, bool fm, hipStream_t s) {
+    const T* B = static_cast<const T*>(y.B);
+    T* Y = static_cast<T*>(y.Y);
+    if (fm)   // Y[t][mb] = sum_n Hc[t][n] B[n][mb]
+        HIP_TRY(gemm_strided<T>(Hc, ldc, 1, B, 1, y.ldb, Y, y.ldy, 1, T_, y.Mb, N, s));
+    else      // Y[mb][t] = sum_n B[mb][n] Hc[t][n]
+        HIP_TRY(gemm_strided<T>(B, y.ldb, 1, Hc, ldc, 1, Y, y.ldy, 1, y.Mb, T_, N, s));
     return ST_OK;
 }
 
@@ -128,7 +157,8 @@ template <>
 int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_solve_opts& o, int n_utt,
                         hipStream_t s) {
     const int c_override = (o.reserved >> 8) & 0xffff;   // C | variant << 8
-    HIP_TRY(fused_pack(w.fl, w.fb, w.At, d.Mk, w.Xt, d.Mk, w.H0, d.Np, s));
+    HIP_TRY(fused_pack_dict(w.fl, w.fb.A1p, w.fb.A2p, w.At, d.Mk, s));
+    HIP_TRY(fused_pack_frames(w.fl, w.fb.Xp, w.Xt, d.Mk, s));
     int first = 1;
     if (o.check_every > 0 && o.stop_rule == EVC_STOP_SKLEARN) {   // error_at_init
         HIP_TRY(fused_iterate(w.fl, w.fb, w.u, d.N, d.T_, 0, 1, 1, w.err2, o.eps_mode, o.eps, o.l1,
@@ -151,18 +181,42 @@ int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_sol
                               o.tol, s));
     }
     if (o.ev_loop_stop) HIP_TRY(hipEventRecord((hipEvent_t)o.ev_loop_stop, s));
-    HIP_TRY(fused_unpack(w.fl, w.fb, w.H0, d.Np, s));
     return ST_OK;
+}
+
+// tail of the fused path: H out of the packed tiles, Y from them
+template <typename T>
+int finish_fused(const Workspace<T>& w, const Dims& d, const evc_solve_opts& o, T* H, int ldh,
+                 const SynthArgs* y, hipStream_t s) {
+    return ST_UNSUPPORTED;
+}
+template <>
+int finish_fused<double>(const Workspace<double>& w, const Dims& d, const evc_solve_opts& o, double* H, int ldh,
+                         const SynthArgs* y, hipStream_t s) {
+    const bool fm = (o.layout == EVC_FRAME_MAJOR);
+    if (H) HIP_TRY(fused_export_h(w.fl, w.fb.Hp, H, ldh, fm ? 1 : 0, d.T_, d.N, s));
+    if (!y) return ST_OK;
+    if (w.packed_synth) {
+        // Bt[n][mb] (zero padded to 32 bins) -> B's V'-operand fragments -> pre-pass -> Y
+        HIP_TRY(copy2d<double>(static_cast<const double*>(y->B), y->ldb, d.N, y->Mb, fm ? 0 : 1, w.Bt, 32, d.Np,
+                               32, 0, s));
+        HIP_TRY(fused_pack_dict(w.flB, w.B1p, w.B2p, w.Bt, 32, s));
+        HIP_TRY(fused_synthesize(w.flB, w.B2p, w.fb.Hp, w.Yp, w.u, d.N, d.T_, y->Mb,
+                                 static_cast<double*>(y->Y), y->ldy, fm ? 1 : 0, s));
+        return ST_OK;
+    }
+    HIP_TRY(fused_export_h(w.fl, w.fb.Hp, w.H0, d.Np, 1, d.T_, d.N, s));
+    return synth_rows<double>(w.H0, d.Np, *y, d.N, d.T_, fm, s);
 }
 
 template <typename T>
 int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int ldh, int M, int N,
                 int T_, const int* utt_offsets, int n_utt, const evc_solve_opts& o, void* ws,
-                size_t ws_bytes, int* n_iter_out, double* err_out, hipStream_t s) {
+                size_t ws_bytes, int* n_iter_out, double* err_out, const SynthArgs* y, hipStream_t s) {
     const T* A = static_cast<const T*>(A_);
     const T* X = static_cast<const T*>(X_);
     T* H = static_cast<T*>(H_);
-    const Dims d = make_dims(M, N, T_, n_utt);
+    const Dims d = make_dims(M, N, T_, n_utt, y ? y->Mb : 0);
     int algo = o.algo == EVC_ALGO_AUTO ? EVC_ALGO_FACTORED : o.algo;
     const int n_slots = n_slots_for(o.iters, o.check_every);
     if (n_slots > MAX_SLOTS) return ST_UNSUPPORTED;
@@ -184,19 +238,25 @@ int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int 
     HIP_TRY(copy2d<T>(A, lda, N, M, fm ? 0 : 1, w.At, d.Mk, d.Np, d.Mk, 0, s));
     HIP_TRY(copy2d<T>(A, lda, M, N, fm ? 1 : 0, w.Am, d.Np, d.Mj, d.Np, 0, s));
     HIP_TRY(copy2d<T>(X, ldx, T_, M, fm ? 0 : 1, w.Xt, d.Mk, d.Tp, d.Mk, 0, s));
-    if (o.init_mode == EVC_INIT_GIVEN) {
-        HIP_TRY(copy2d<T>(H, ldh, T_, N, fm ? 0 : 1, w.H0, d.Np, d.Tp, d.Np, 0, s));
-    } else {
-        if (o.init_mode == EVC_INIT_SKLEARN) HIP_TRY(utt_sklearn_h0<T>(w.Xt, d.Mk, M, N, w.u, n_utt, s));
-        else HIP_TRY(utt_const_h0(w.u, n_utt, o.init_value, s));
-        HIP_TRY(fill_h0<T>(w.H0, d.Np, d.Tp, N, T_, w.u, s));
-    }
+    if (o.init_mode == EVC_INIT_SKLEARN) HIP_TRY(utt_sklearn_h0<T>(w.Xt, d.Mk, M, N, w.u, n_utt, s));
+    else if (o.init_mode == EVC_INIT_CONST) HIP_TRY(utt_const_h0(w.u, n_utt, o.init_value, s));
 
-    if (fused) {
+    if (fused) {     // activations live in the packed tile layout from start to finish
+        if (o.init_mode == EVC_INIT_GIVEN)
+            HIP_TRY(fused_import_h(w.fl, w.fb.Hp, reinterpret_cast<const double*>(H), ldh, fm ? 1 : 0, T_, N, s));
+        else
+            HIP_TRY(fused_fill_h(w.fl, w.fb.Hp, N, T_, w.u, s));
         int st = solve_fused(w, d, o, n_utt, s);
         if (st) return st;
-        return finish<T>(w, d, o, w.H0, H, ldh, n_utt, n_slots, n_iter_out, err_out, s);
+        st = finish_fused<T>(w, d, o, H, ldh, y, s);
+        if (st) return st;
+        return copy_back(w.u, n_utt, n_slots, n_iter_out, err_out, s);
     }
+
+    if (o.init_mode == EVC_INIT_GIVEN)
+        HIP_TRY(copy2d<T>(H, ldh, T_, N, fm ? 0 : 1, w.H0, d.Np, d.Tp, d.Np, 0, s));
+    else
+        HIP_TRY(fill_h0<T>(w.H0, d.Np, d.Tp, N, T_, w.u, s));
 
     // ---- numerator (and Gram matrix) ----
     const bool gram = (algo == EVC_ALGO_GRAM || algo == EVC_ALGO_LITERAL);
@@ -247,14 +307,19 @@ int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int 
     }
 
     if (o.ev_loop_stop) HIP_TRY(hipEventRecord((hipEvent_t)o.ev_loop_stop, s));
-    return finish<T>(w, d, o, Hc, H, ldh, n_utt, n_slots, n_iter_out, err_out, s);
+    if (H) HIP_TRY(copy2d<T>(Hc, d.Np, d.T_, d.N, 0, H, ldh, d.T_, d.N, fm ? 0 : 1, s));
+    if (y) {
+        int st = synth_rows<T>(Hc, d.Np, *y, d.N, d.T_, fm, s);
+        if (st) return st;
+    }
+    return copy_back(w.u, n_utt, n_slots, n_iter_out, err_out, s);
 }
 
-template <typename T> size_t workspace_typed(int M, int N, int T_, int n_utt, int algo) {
-    const Dims d = make_dims(M, N, T_, n_utt);
+template <typename T> size_t workspace_typed(int M, int Mb, int N, int T_, int n_utt, int algo) {
+    const Dims d = make_dims(M, N, T_, n_utt, Mb);
     const int al = algo == EVC_ALGO_AUTO ? EVC_ALGO_FACTORED : algo;
     const int dt = sizeof(T) == 8 ? EVC_F64 : EVC_F32;
-    // the generic carve is never smaller than the fused one minus the packed arrays; take the max
+    // callers may disable the fused path per call, so the query covers both carvings
     const size_t a = carve<T>(nullptr, d, al, MAX_SLOTS, false).bytes;
     const size_t b = use_fused(M, N, T_, dt, al) ? carve<T>(nullptr, d, al, MAX_SLOTS, true).bytes : 0;
     return a > b ? a : b;
@@ -289,18 +354,18 @@ int evc_device_count(void) {
     return e == hipSuccess ? n : -(int)e;
 }
 
-size_t evc_workspace_bytes(int M, int N, int T, int n_utt, int dtype, int algo) {
-    if (M < 0 || N < 0 || T < 0 || n_utt < 1) return 0;
+size_t evc_workspace_bytes(int M, int Mb, int N, int T, int n_utt, int dtype, int algo) {
+    if (M < 0 || Mb < 0 || N < 0 || T < 0 || n_utt < 1) return 0;
     if (algo < EVC_ALGO_GRAM || algo > EVC_ALGO_AUTO) return 0;
-    if (dtype == EVC_F64) return workspace_typed<double>(M, N, T, n_utt, algo);
-    if (dtype == EVC_F32) return workspace_typed<float>(M, N, T, n_utt, algo);
+    if (dtype == EVC_F64) return workspace_typed<double>(M, Mb, N, T, n_utt, algo);
+    if (dtype == EVC_F32) return workspace_typed<float>(M, Mb, N, T, n_utt, algo);
     return 0;
 }
 
-int evc_nmf_solve(const void* A, int lda, const void* X, int ldx, void* H, int ldh, int M, int N,
-                  int T, const int* utt_offsets, int n_utt, const evc_solve_opts* opts,
-                  void* workspace, size_t workspace_bytes, int* n_iter_out, double* err_out,
-                  evc_stream_t stream) {
+static int solve_checked(const void* A, int lda, const void* X, int ldx, void* H, int ldh, int M, int N,
+                        int T, const int* utt_offsets, int n_utt, const evc_solve_opts* opts,
+                        void* workspace, size_t workspace_bytes, int* n_iter_out, double* err_out,
+                        const SynthArgs* y, evc_stream_t stream) {
     if (!opts || opts->struct_bytes != (int)sizeof(evc_solve_opts)) return ST_BADARG;
     const evc_solve_opts& o = *opts;
     if (M < 1 || N < 1 || T < 0 || n_utt < 1 || o.iters < 0) return ST_BADARG;
@@ -313,12 +378,16 @@ int evc_nmf_solve(const void* A, int lda, const void* X, int ldx, void* H, int l
     if (o.check_every < 0) return ST_BADARG;
     if (o.stop_rule != EVC_STOP_NONE && o.check_every == 0) return ST_BADARG;
     if (!(o.l1 >= 0.0)) return ST_BADARG;
+    if (y && y->Mb < 1) return ST_BADARG;
     if (T == 0) {
         if (n_iter_out) for (int i = 0; i < n_utt; ++i) n_iter_out[i] = 0;
         return ST_OK;
     }
-    if (!A || !X || !H || !workspace) return ST_BADARG;
-    if (bad_ld(o.layout, lda, N, M) || bad_ld(o.layout, ldx, T, M) || bad_ld(o.layout, ldh, T, N))
+    if (!A || !X || !workspace) return ST_BADARG;
+    if (!H && (!y || o.init_mode == EVC_INIT_GIVEN)) return ST_BADARG;   // H may be omitted by evc_nmf_convert only
+    if (bad_ld(o.layout, lda, N, M) || bad_ld(o.layout, ldx, T, M) || (H && bad_ld(o.layout, ldh, T, N)))
+        return ST_BADARG;
+    if (y && (!y->B || !y->Y || bad_ld(o.layout, y->ldb, N, y->Mb) || bad_ld(o.layout, y->ldy, T, y->Mb)))
         return ST_BADARG;
     if (utt_offsets) {
         if (utt_offsets[0] != 0 || utt_offsets[n_utt] != T) return ST_BADARG;
@@ -330,9 +399,26 @@ int evc_nmf_solve(const void* A, int lda, const void* X, int ldx, void* H, int l
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (o.dtype == EVC_F64)
         return solve_typed<double>(A, lda, X, ldx, H, ldh, M, N, T, utt_offsets, n_utt, o, workspace,
-                                   workspace_bytes, n_iter_out, err_out, s);
+                                   workspace_bytes, n_iter_out, err_out, y, s);
     return solve_typed<float>(A, lda, X, ldx, H, ldh, M, N, T, utt_offsets, n_utt, o, workspace,
-                              workspace_bytes, n_iter_out, err_out, s);
+                              workspace_bytes, n_iter_out, err_out, y, s);
+}
+
+int evc_nmf_solve(const void* A, int lda, const void* X, int ldx, void* H, int ldh, int M, int N,
+                  int T, const int* utt_offsets, int n_utt, const evc_solve_opts* opts,
+                  void* workspace, size_t workspace_bytes, int* n_iter_out, double* err_out,
+                  evc_stream_t stream) {
+    return solve_checked(A, lda, X, ldx, H, ldh, M, N, T, utt_offsets, n_utt, opts, workspace,
+                         workspace_bytes, n_iter_out, err_out, nullptr, stream);
+}
+
+int evc_nmf_convert(const void* A, int lda, const void* X, int ldx, const void* B, int ldb, void* H,
+                    int ldh, void* Y, int ldy, int M, int Mb, int N, int T, const int* utt_offsets,
+                    int n_utt, const evc_solve_opts* opts, void* workspace, size_t workspace_bytes,
+                    int* n_iter_out, double* err_out, evc_stream_t stream) {
+    const SynthArgs y{B, ldb, Y, ldy, Mb};
+    return solve_checked(A, lda, X, ldx, H, ldh, M, N, T, utt_offsets, n_utt, opts, workspace,
+                         workspace_bytes, n_iter_out, err_out, &y, stream);
 }
 
 int evc_synthesize(const void* B, int ldb, const void* H, int ldh, void* Y, int ldy, int Mb, int N,
@@ -373,7 +459,7 @@ int evc_residual(const void* A, int lda, const void* X, int ldx, const void* H, 
     if (bad_ld(layout, lda, N, M) || bad_ld(layout, ldx, T, M) || bad_ld(layout, ldh, T, N))
         return ST_BADARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const Dims d = make_dims(M, N, T, 1);
+    const Dims d = make_dims(M, N, T, 1, 0);
     const bool fm = (layout == EVC_FRAME_MAJOR);
 #define EVC_RESID(TT)                                                                              \
     {                                                                                              \

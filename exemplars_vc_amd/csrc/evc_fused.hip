@@ -74,6 +74,81 @@ __global__ void k_pack_h(double* __restrict__ Ht, int ldh, long TTp, int NT, f64
     else *reinterpret_cast<f64x2*>(src) = Hp[gid];
 }
 
+// Hp <-> the caller's H (either layout, any strides): one wavefront per 16x16 tile, staged through
+// a wave-private LDS tile so that the caller-side accesses are whole 128-byte rows.  Out-of-range
+// frames / exemplars read as 0 and are not written.
+//   TO_PACKED: caller -> Hp (import of a given H0);  else: Hp -> caller (export of the result)
+template <bool TO_PACKED>
+__global__ __launch_bounds__(256) void k_hp_io(double* __restrict__ H, long ldh, int frame_major, int T_,
+                                                int N, f64x2* __restrict__ Hp, long n_tiles, int NT) {
+    __shared__ double buf[4][16][17];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long tile = (long)blockIdx.x * 4 + w;
+    if (tile >= n_tiles) return;
+    const long tt = tile / NT, j = tile % NT;
+    const long t0 = 16 * tt, n0 = 16 * j;
+    double (*b)[17] = buf[w];                    // b[row][col]: row = caller's outer index within the tile
+    const int pt = lane & 15, pq = lane >> 4;    // packed order: frame pt, exemplars 4 pq + r
+    const int rr = lane >> 2, rc = (lane & 3) * 4;   // row order: row rr, columns rc .. rc+3
+    if (TO_PACKED) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const long t = frame_major ? t0 + rr : t0 + rc + e, n = frame_major ? n0 + rc + e : n0 + rr;
+            double v = 0.0;
+            if (t < T_ && n < N) v = frame_major ? H[t * ldh + n] : H[n * ldh + t];
+            b[rr][rc + e] = v;
+        }
+        double h[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = frame_major ? b[pt][4 * pq + r] : b[4 * pq + r][pt];
+        Hp[(tile * 2 + 0) * 64 + lane] = f64x2{h[0], h[1]};
+        Hp[(tile * 2 + 1) * 64 + lane] = f64x2{h[2], h[3]};
+    } else {
+        const f64x2 h01 = Hp[(tile * 2 + 0) * 64 + lane], h23 = Hp[(tile * 2 + 1) * 64 + lane];
+        const double h[4] = {h01[0], h01[1], h23[0], h23[1]};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (frame_major) b[pt][4 * pq + r] = h[r]; else b[4 * pq + r][pt] = h[r];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const long t = frame_major ? t0 + rr : t0 + rc + e, n = frame_major ? n0 + rc + e : n0 + rr;
+            if (t < T_ && n < N) {
+                if (frame_major) H[t * ldh + n] = b[rr][rc + e]; else H[n * ldh + t] = b[rr][rc + e];
+            }
+        }
+    }
+}
+
+// Hp <- per-utterance constant (EVC_INIT_SKLEARN / CONST), zero in the padding
+__global__ __launch_bounds__(256) void k_fill_hp(f64x2* __restrict__ Hp, long n_tiles, int NT, int N, int T_,
+                                                  UttState u) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n_tiles * 128) return;
+    const int l = gid & 63, p = (gid >> 6) & 1;
+    const long tile = gid >> 7;
+    const long tt = tile / NT, j = tile % NT;
+    const long t = 16 * tt + (l & 15);
+    const long n = 16 * j + 4 * (l >> 4) + 2 * p;
+    double v = 0.0;
+    if (t < T_) { const int id = u.frame_utt[t]; if (id >= 0) v = u.h0[id]; }
+    Hp[gid] = f64x2{n < N ? v : 0.0, n + 1 < N ? v : 0.0};
+}
+
+// Y (caller layout) <- Yp[tt][s][l] = Y[bin_of(s, l>>4)][16 tt + (l&15)]   (accumulator order of B H)
+__global__ __launch_bounds__(256) void k_unpack_y(const double* __restrict__ Yp, long n_elems, int msteps, int Mb,
+                                                   int T_, double* __restrict__ Y, long ldy, int frame_major) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n_elems) return;
+    const int l = gid & 63, s = (gid >> 6) % msteps;
+    const long tt = (gid >> 6) / msteps;
+    const long t = 16 * tt + (l & 15);
+    const int mb = bin_of(s, l >> 4);
+    if (t >= T_ || mb >= Mb) return;
+    const double v = Yp[(tt * 8 + s) * 64 + l];
+    if (frame_major) Y[t * ldy + mb] = v; else Y[(long)mb * ldy + t] = v;
+}
+
 // Registers of one 16-exemplar dictionary tile (both operand orders) and of the C activation
 // tiles that go with it; two of these ping-pong so that tile j+NW is in flight while tile j is
 // on the matrix cores.
@@ -110,7 +185,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused_mu(FusedArgs a) {
         const long t = 16 * (tt0 + c) + (lane & 15);
         int u = -1;
         if (tt0 + c < a.TT && t < a.T_) u = a.frame_utt[t];
-        live[c] = (u >= 0) && (a.active[u] != 0);
+        live[c] = (u >= 0) && (a.force_live || a.active[u] != 0);
         any |= live[c];
     }
     if (!__syncthreads_or(any)) return;
@@ -326,25 +401,41 @@ FusedLayout fused_layout(int M, int N, int T_) {
     return f;
 }
 
-hipError_t fused_pack(const FusedLayout& f, const FusedBuffers& b, const double* At, int ldA,
-                      const double* Xt, int ldx, double* Ht, int ldh, hipStream_t s) {
-    {
-        const long n = (long)f.a1 + (long)f.a2;
-        hipLaunchKernelGGL(k_pack_dict, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, At, ldA, f.NT,
-                           f.msteps, f.mtiles, b.A1p, b.A2p);
-    }
-    hipLaunchKernelGGL(k_pack_frames, dim3((unsigned)((f.xp + 255) / 256)), dim3(256), 0, s, Xt, ldx,
-                       (long)f.TTp, f.msteps, b.Xp);
-    const long nh = (long)f.TTp * f.NT * 128;
-    hipLaunchKernelGGL((k_pack_h<true>), dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, s, Ht, ldh,
-                       (long)f.TTp, f.NT, reinterpret_cast<f64x2*>(b.Hp));
+hipError_t fused_pack_dict(const FusedLayout& f, double* A1p, double* A2p, const double* At, int ldA,
+                           hipStream_t s) {
+    const long n = (long)f.a1 + (long)f.a2;
+    hipLaunchKernelGGL(k_pack_dict, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, At, ldA, f.NT, f.msteps,
+                       f.mtiles, A1p, A2p);
     return hipGetLastError();
 }
 
-hipError_t fused_unpack(const FusedLayout& f, const FusedBuffers& b, double* Ht, int ldh, hipStream_t s) {
-    const long nh = (long)f.TTp * f.NT * 128;
-    hipLaunchKernelGGL((k_pack_h<false>), dim3((unsigned)((nh + 255) / 256)), dim3(256), 0, s, Ht, ldh,
-                       (long)f.TTp, f.NT, reinterpret_cast<f64x2*>(b.Hp));
+hipError_t fused_pack_frames(const FusedLayout& f, double* Xp, const double* Xt, int ldx, hipStream_t s) {
+    hipLaunchKernelGGL(k_pack_frames, dim3((unsigned)((f.xp + 255) / 256)), dim3(256), 0, s, Xt, ldx,
+                       (long)f.TTp, f.msteps, Xp);
+    return hipGetLastError();
+}
+
+// H: the caller's activation matrix (frame_major: H[t*ldh+n], else H[n*ldh+t])
+hipError_t fused_import_h(const FusedLayout& f, double* Hp, const double* H, long ldh, int frame_major, int T_,
+                          int N, hipStream_t s) {
+    const long tiles = (long)f.TTp * f.NT;
+    hipLaunchKernelGGL((k_hp_io<true>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s,
+                       const_cast<double*>(H), ldh, frame_major, T_, N, reinterpret_cast<f64x2*>(Hp), tiles, f.NT);
+    return hipGetLastError();
+}
+
+hipError_t fused_export_h(const FusedLayout& f, const double* Hp, double* H, long ldh, int frame_major, int T_,
+                          int N, hipStream_t s) {
+    const long tiles = (long)f.TT * f.NT;
+    hipLaunchKernelGGL((k_hp_io<false>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, H, ldh, frame_major,
+                       T_, N, reinterpret_cast<f64x2*>(const_cast<double*>(Hp)), tiles, f.NT);
+    return hipGetLastError();
+}
+
+hipError_t fused_fill_h(const FusedLayout& f, double* Hp, int N, int T_, const UttState& u, hipStream_t s) {
+    const long tiles = (long)f.TTp * f.NT;
+    hipLaunchKernelGGL(k_fill_hp, dim3((unsigned)((tiles * 128 + 255) / 256)), dim3(256), 0, s,
+                       reinterpret_cast<f64x2*>(Hp), tiles, f.NT, N, T_, u);
     return hipGetLastError();
 }
 
@@ -418,7 +509,7 @@ hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttS
     a.A1p = b.A1p; a.A2p = b.A2p; a.Xp = b.Xp; a.Hp = reinterpret_cast<f64x2*>(b.Hp); a.Vp = b.Vp;
     a.err2 = err2; a.frame_utt = u.frame_utt; a.active = u.active;
     a.NT = f.NT; a.TT = f.TT; a.N = N; a.T_ = T_;
-    a.iters = iters; a.first = first; a.write_err = write_err; a.skip_all_live = 0;
+    a.iters = iters; a.first = first; a.write_err = write_err; a.skip_all_live = 0; a.force_live = 0;
     a.eps_mode = eps_mode; a.eps = eps; a.l1 = l1;
     const bool resident = variant == 0 && fused_res_supported(N, eps_mode);
     if (!resident) return launch_general(f, a, T_, variant, s);
@@ -435,6 +526,26 @@ hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttS
     if (e != hipSuccess || all_live_known) return e;
     a.skip_all_live = 1;         // workgroups holding frames of stopped utterances
     return launch_general(f, a, T_, 1, s);
+}
+
+// Y = B H straight from the packed activations: the V pre-pass with B's fragments in place of A's
+// (HBM-bound on Hp), then a small unpack into the caller's layout.  fb.A2p must hold B's fragments.
+hipError_t fused_synthesize(const FusedLayout& fB, const double* B2p, const double* Hp, double* Yp,
+                            const UttState& u, int N, int T_, int Mb, double* Y, long ldy, int frame_major,
+                            hipStream_t s) {
+    FusedArgs a;
+    a.A1p = B2p; a.A2p = B2p; a.Xp = Yp;        // A1p / Xp are not used by a pure pre-pass
+    a.Hp = reinterpret_cast<f64x2*>(const_cast<double*>(Hp)); a.Vp = Yp;
+    a.err2 = nullptr; a.frame_utt = u.frame_utt; a.active = u.active;
+    a.NT = fB.NT; a.TT = fB.TT; a.N = N; a.T_ = T_;
+    a.iters = 0; a.first = 1; a.write_err = 0; a.skip_all_live = 0; a.force_live = 1;
+    a.eps_mode = EVC_EPS_ADD; a.eps = 0; a.l1 = 0;
+    hipError_t e = dispatch_msteps<1, 8, false>(fB.msteps, a, s);
+    if (e != hipSuccess) return e;
+    const long n = (long)fB.TT * fB.msteps * 64;
+    hipLaunchKernelGGL(k_unpack_y, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Yp, n, fB.msteps, Mb, T_,
+                       Y, ldy, frame_major);
+    return hipGetLastError();
 }
 
 }  // namespace evc

@@ -40,6 +40,7 @@ struct FusedArgs {
     int first;               // 1: V is computed from H by a pre-pass, 0: V is loaded from Vp
     int write_err;
     int skip_all_live;       // 1: workgroups whose frames are all live were done by k_fused_res
+    int force_live;          // 1: ignore the utterances' active flags (synthesis pre-pass)
     int eps_mode;
     double eps, l1;
 };

@@ -130,10 +130,20 @@ struct FusedBuffers {
 };
 bool fused_supported(int M, int N, int T_, int dtype);
 FusedLayout fused_layout(int M, int N, int T_);
-// At[n][m] / Xt[t][m] / Ht[t][n]: the zero-padded frames-as-rows workspace arrays
-hipError_t fused_pack(const FusedLayout& f, const FusedBuffers& b, const double* At, int ldA,
-                      const double* Xt, int ldx, double* Ht, int ldh, hipStream_t s);
-hipError_t fused_unpack(const FusedLayout& f, const FusedBuffers& b, double* Ht, int ldh, hipStream_t s);
+// At[n][m] / Xt[t][m]: the zero-padded frames-as-rows workspace arrays
+hipError_t fused_pack_dict(const FusedLayout& f, double* A1p, double* A2p, const double* At, int ldA,
+                           hipStream_t s);
+hipError_t fused_pack_frames(const FusedLayout& f, double* Xp, const double* Xt, int ldx, hipStream_t s);
+// packed activations <-> the caller's H (frame_major: H[t*ldh+n], else H[n*ldh+t]); per-utterance constant fill
+hipError_t fused_import_h(const FusedLayout& f, double* Hp, const double* H, long ldh, int frame_major, int T_,
+                          int N, hipStream_t s);
+hipError_t fused_export_h(const FusedLayout& f, const double* Hp, double* H, long ldh, int frame_major, int T_,
+                          int N, hipStream_t s);
+hipError_t fused_fill_h(const FusedLayout& f, double* Hp, int N, int T_, const UttState& u, hipStream_t s);
+// Y = B H from the packed activations (fB: layout for (Mb, N, T); B2p: B's V'-operand fragments)
+hipError_t fused_synthesize(const FusedLayout& fB, const double* B2p, const double* Hp, double* Yp,
+                            const UttState& u, int N, int T_, int Mb, double* Y, long ldy, int frame_major,
+                            hipStream_t s);
 // `iters` updates in one launch.  first: V is built from H by a pre-pass (else carried over in
 // Vp from the previous launch); write_err: per-frame squared residuals of the final H -> err2.
 hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttState& u, int N, int T_,

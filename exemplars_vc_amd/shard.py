@@ -42,12 +42,11 @@ def convert_utterances(X_list, A, B, *, iters=100, tol=0.0, eps_mode="zero_repla
     offs = np.concatenate([[0], np.cumsum([len(x) for x in X_list])]).astype(np.int32)
     X = np.concatenate([np.asarray(x) for x in X_list], axis=0)
     if solver is None:
-        from .solver import solve_activations, synthesize
-        act = solve_activations(A, X, layout="frame_major", iters=iters, eps_mode=eps_mode,
-                                init=init, algo=algo, utt_offsets=offs, device=device,
-                                check_every=10 if tol > 0 else 0,
-                                stop_rule="sklearn" if tol > 0 else "none", tol=tol)
-        Y = synthesize(B, act, layout="frame_major", device=device)
+        from .solver import convert
+        Y = convert(A, X, B, want_h=False, layout="frame_major", iters=iters, eps_mode=eps_mode,
+                    init=init, algo=algo, utt_offsets=offs, device=device,
+                    check_every=10 if tol > 0 else 0,
+                    stop_rule="sklearn" if tol > 0 else "none", tol=tol)
     else:
         act = solver(X, offs)
         Y = act @ np.asarray(B)

@@ -103,22 +103,35 @@ def _pick_dtype(dtype, *arrs):
     raise ValueError(f"unsupported dtype {dtype!r}")
 
 
-def workspace_bytes(M, N, T, n_utt=1, dtype="f64", algo="auto"):
+def workspace_bytes(M, N, T, n_utt=1, dtype="f64", algo="auto", Mb=0):
     _, code = _pick_dtype(dtype)
-    return int(_lib.lib().evc_workspace_bytes(M, N, T, n_utt, code, _ALGOS[algo]))
+    return int(_lib.lib().evc_workspace_bytes(M, Mb, N, T, n_utt, code, _ALGOS[algo]))
 
 
-def solve_activations(A, X, H0=None, *, layout="bin_major", iters=100, eps_mode="add", eps=None,
-                      l1=0.0, algo="auto", init=None, init_value=0.0, check_every=0,
-                      stop_rule="none", tol=0.0, utt_offsets: Optional[Sequence[int]] = None,
-                      dtype=None, device=None, info=False, out=None, loop_events=None,
-                      fused=True, fused_c=0):
+def solve_activations(A, X, H0=None, **kw):
     """H <- H (.) A^T X (/) guard(A^T A H + l1), `iters` times, on the GPU.
 
     Returns H in the caller's orientation (numpy in -> numpy out, device tensor in -> device
     tensor out); with info=True also a dict(n_iter=int array per utterance, err=array
     [n_utt, 1+iters//check_every] of residuals, NaN where not evaluated).
+    Keywords: see `_solve`.
     """
+    return _solve(A, X, H0, None, **kw)
+
+
+def convert(A, X, B, H0=None, *, want_h=True, **kw):
+    """Activation solve followed by the synthesis Y = B H in one launch sequence
+    (factorize() + convert() of 04_align_n_nmf.py).  Returns (H, Y), or Y alone with
+    want_h=False (the activations then never leave the solver's tile layout); with info=True
+    the info dict is appended."""
+    return _solve(A, X, H0, B, want_h=want_h, **kw)
+
+
+def _solve(A, X, H0, B, *, layout="bin_major", iters=100, eps_mode="add", eps=None,
+           l1=0.0, algo="auto", init=None, init_value=0.0, check_every=0,
+           stop_rule="none", tol=0.0, utt_offsets: Optional[Sequence[int]] = None,
+           dtype=None, device=None, info=False, out=None, loop_events=None,
+           fused=True, fused_c=0, want_h=True, out_y=None):
     torch = _torch()
     device = require_device(device)
     L = _lib.lib()
@@ -136,6 +149,14 @@ def solve_activations(A, X, H0=None, *, layout="bin_major", iters=100, eps_mode=
         hshape = (T, N)
     if M2 != M:
         raise ValueError(f"A and X disagree on the number of bins: {M} vs {M2}")
+    Mb = 0
+    if B is not None:
+        B_d, _ = _to_dev(B, tdtype, device)
+        Mb, N2 = B_d.shape if lay == _lib.BIN_MAJOR else B_d.shape[::-1]
+        if N2 != N:
+            raise ValueError(f"A and B disagree on the number of exemplars: {N} vs {N2}")
+        yshape = (Mb, T) if lay == _lib.BIN_MAJOR else (T, Mb)
+        Y_d = out_y if out_y is not None else torch.empty(yshape, dtype=tdtype, device=device)
     if init is None:
         init = "given" if H0 is not None else "sklearn"
     if init == "given":
@@ -149,9 +170,12 @@ def solve_activations(A, X, H0=None, *, layout="bin_major", iters=100, eps_mode=
             H_d = out
         elif isinstance(H0, torch.Tensor) and H_d.data_ptr() == H0.data_ptr():
             H_d = H_d.clone()       # never clobber the caller's H0
+    elif B is not None and not want_h:
+        H_d = None
     else:
         H_d = out if out is not None else torch.empty(hshape, dtype=tdtype, device=device)
-    if tuple(H_d.shape) != hshape or H_d.dtype != tdtype or (H_d.shape[1] > 1 and H_d.stride(1) != 1):
+    if H_d is not None and (tuple(H_d.shape) != hshape or H_d.dtype != tdtype
+                            or (H_d.shape[1] > 1 and H_d.stride(1) != 1)):
         raise ValueError("`out` must be a contiguous device tensor of the activation shape/dtype")
 
     if utt_offsets is None:
@@ -177,24 +201,35 @@ def solve_activations(A, X, H0=None, *, layout="bin_major", iters=100, eps_mode=
         opts.ev_loop_start = int(loop_events[0].cuda_event)
         opts.ev_loop_stop = int(loop_events[1].cuda_event)
 
-    ws_bytes = int(L.evc_workspace_bytes(M, N, T, n_utt, dcode, opts.algo))
+    ws_bytes = int(L.evc_workspace_bytes(M, Mb, N, T, n_utt, dcode, opts.algo))
     ws = _workspace(ws_bytes, device)
     n_slots = 1 + (iters // check_every if check_every > 0 else 0)
     n_iter = np.zeros(n_utt, dtype=np.int32) if info else None
     err = np.full((n_utt, n_slots), np.nan) if info else None
+    ni_p = n_iter.ctypes.data_as(C.POINTER(C.c_int)) if info else None
+    er_p = err.ctypes.data_as(C.POINTER(C.c_double)) if info else None
+    h_ptr, h_ld = (H_d.data_ptr(), _ld(H_d)) if H_d is not None else (None, 0)
     with torch.cuda.device(device):
         stream = torch.cuda.current_stream(device).cuda_stream
-        st = L.evc_nmf_solve(
-            A_d.data_ptr(), _ld(A_d), X_d.data_ptr(), _ld(X_d), H_d.data_ptr(), _ld(H_d),
-            M, N, T, off_ptr, n_utt, C.byref(opts), ws.data_ptr(), ws.numel(),
-            n_iter.ctypes.data_as(C.POINTER(C.c_int)) if info else None,
-            err.ctypes.data_as(C.POINTER(C.c_double)) if info else None,
-            C.c_void_p(stream))
-    _lib.check(st, "evc_nmf_solve")
-    H_out = H_d.cpu().numpy() if x_np and out is None else H_d
+        if B is None:
+            st = L.evc_nmf_solve(
+                A_d.data_ptr(), _ld(A_d), X_d.data_ptr(), _ld(X_d), h_ptr, h_ld,
+                M, N, T, off_ptr, n_utt, C.byref(opts), ws.data_ptr(), ws.numel(), ni_p, er_p,
+                C.c_void_p(stream))
+        else:
+            st = L.evc_nmf_convert(
+                A_d.data_ptr(), _ld(A_d), X_d.data_ptr(), _ld(X_d), B_d.data_ptr(), _ld(B_d),
+                h_ptr, h_ld, Y_d.data_ptr(), _ld(Y_d), M, Mb, N, T, off_ptr, n_utt, C.byref(opts),
+                ws.data_ptr(), ws.numel(), ni_p, er_p, C.c_void_p(stream))
+    _lib.check(st, "evc_nmf_solve" if B is None else "evc_nmf_convert")
+    to_np = x_np and out is None
+    H_out = None if H_d is None else (H_d.cpu().numpy() if to_np else H_d)
+    res = [H_out] if B is None else ([H_out] if want_h else [])
+    if B is not None:
+        res.append(Y_d.cpu().numpy() if (x_np and out_y is None) else Y_d)
     if info:
-        return H_out, {"n_iter": n_iter, "err": err}
-    return H_out
+        res.append({"n_iter": n_iter, "err": err})
+    return res[0] if len(res) == 1 else tuple(res)
 
 
 def synthesize(B, H, *, layout="bin_major", dtype=None, device=None):
@@ -243,7 +278,7 @@ def frame_residuals(A, X, H, *, layout="bin_major", dtype=None, device=None):
         N, M = A_d.shape
         T = X_d.shape[0]
     err2 = torch.zeros(max(T, 1), dtype=torch.float64, device=device)
-    ws_bytes = int(L.evc_workspace_bytes(M, N, T, 1, dcode, _lib.ALGO_FACTORED))
+    ws_bytes = int(L.evc_workspace_bytes(M, 0, N, T, 1, dcode, _lib.ALGO_GRAM))
     ws = _workspace(ws_bytes, device)
     with torch.cuda.device(device):
         stream = torch.cuda.current_stream(device).cuda_stream

@@ -12,6 +12,7 @@
  *                     - pymf NMF._update_h / factorize  pymf/nmf.py:66-70, pymf/base.py:208-270
  *                     - nmf_tool NMF.NMF (mu, initW)    nmf_tool/nmf.py:36-40,57-67
  *   evc_synthesize  replaces np.matmul(H.T, B) in convert()  04_align_n_nmf.py:371-373,391
+ *   evc_nmf_convert both of the above back to back (factorize() + convert(), :452-455)
  *   evc_residual    replaces sklearn _beta_divergence(beta=2, square_root=True)
  *                   (_nmf.py:85-135) and pymf frobenius_norm (pymf/base.py:144-165)
  *
@@ -106,9 +107,10 @@ const char* evc_strerror(int status);
 /* number of GPUs visible to the library (hipGetDeviceCount); <0 on failure */
 int evc_device_count(void);
 
-/* Bytes of device workspace evc_nmf_solve needs for a problem of this size.
+/* Bytes of device workspace evc_nmf_solve / evc_nmf_convert / evc_residual need for a problem of
+ * this size.  Mb: bins of the target dictionary B for evc_nmf_convert, 0 otherwise.
  * n_utt is the number of utterances the T frames are split into (>= 1). */
-size_t evc_workspace_bytes(int M, int N, int T, int n_utt, int dtype, int algo);
+size_t evc_workspace_bytes(int M, int Mb, int N, int T, int n_utt, int dtype, int algo);
 
 /* Solve X ~ A H for H >= 0 with A fixed: `iters` multiplicative updates
  *   H <- H (.) A^T X (/) guard(A^T A H + l1).
@@ -132,13 +134,27 @@ int evc_nmf_solve(const void* A, int lda, const void* X, int ldx, void* H, int l
                   int* n_iter_out, double* err_out,
                   evc_stream_t stream);
 
+/* evc_nmf_solve followed by Y = B H in one launch sequence: factorize() + convert() of
+ * 04_align_n_nmf.py:218-333,336-393 (the __main__ sequence :452-455).  The synthesis reads the
+ * activations in the solver's own tile layout, so H is not re-read in the caller's layout; H may be
+ * NULL when only Y is wanted (not with EVC_INIT_GIVEN).  B: Mb x N target exemplars, Y: Mb x T,
+ * both in opts->layout.  Workspace: evc_workspace_bytes(M, Mb, N, T, ...). */
+int evc_nmf_convert(const void* A, int lda, const void* X, int ldx, const void* B, int ldb,
+                    void* H, int ldh, void* Y, int ldy,
+                    int M, int Mb, int N, int T,
+                    const int* utt_offsets, int n_utt,
+                    const evc_solve_opts* opts,
+                    void* workspace, size_t workspace_bytes,
+                    int* n_iter_out, double* err_out,
+                    evc_stream_t stream);
+
 /* Y = B H  (04_align_n_nmf.py:391: np.matmul(H.T, B) in FRAME_MAJOR orientation). */
 int evc_synthesize(const void* B, int ldb, const void* H, int ldh, void* Y, int ldy,
                    int Mb, int N, int T, int layout, int dtype, evc_stream_t stream);
 
 /* err2_out[t] (device, T values of `dtype`... always double) = sum_m (X[m,t] - (A H)[m,t])^2.
  * The Frobenius residual of a set of frames is sqrt of the sum of its entries.
- * workspace: evc_workspace_bytes(M, N, T, 1, dtype, EVC_ALGO_FACTORED) suffices.       */
+ * workspace: evc_workspace_bytes(M, 0, N, T, 1, dtype, EVC_ALGO_GRAM) suffices.            */
 int evc_residual(const void* A, int lda, const void* X, int ldx, const void* H, int ldh,
                  int M, int N, int T, int layout, int dtype,
                  double* err2_out, void* workspace, size_t workspace_bytes,

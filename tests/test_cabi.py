@@ -40,12 +40,13 @@ def test_strerror_and_workspace_queries():
     _lib, L = lib()
     assert _lib.strerror(0) == "ok"
     assert "argument" in _lib.strerror(-1) and "workspace" in _lib.strerror(-2)
-    small = L.evc_workspace_bytes(25, 512, 688, 1, _lib.F64, _lib.ALGO_FACTORED)
-    big = L.evc_workspace_bytes(25, 4096, 688, 1, _lib.F64, _lib.ALGO_FACTORED)
-    gram = L.evc_workspace_bytes(25, 4096, 688, 1, _lib.F64, _lib.ALGO_GRAM)
+    small = L.evc_workspace_bytes(25, 0, 512, 688, 1, _lib.F64, _lib.ALGO_FACTORED)
+    big = L.evc_workspace_bytes(25, 0, 4096, 688, 1, _lib.F64, _lib.ALGO_FACTORED)
+    gram = L.evc_workspace_bytes(25, 0, 4096, 688, 1, _lib.F64, _lib.ALGO_GRAM)
     assert 0 < small < big < gram
-    assert L.evc_workspace_bytes(25, 4096, 688, 1, _lib.F32, _lib.ALGO_GRAM) < gram
-    assert L.evc_workspace_bytes(-1, 1, 1, 1, 0, 0) == 0 and L.evc_workspace_bytes(1, 1, 1, 1, 7, 0) == 0
+    assert L.evc_workspace_bytes(25, 25, 4096, 688, 1, _lib.F64, _lib.ALGO_FACTORED) >= big
+    assert L.evc_workspace_bytes(25, 0, 4096, 688, 1, _lib.F32, _lib.ALGO_GRAM) < gram
+    assert L.evc_workspace_bytes(-1, 0, 1, 1, 1, 0, 0) == 0 and L.evc_workspace_bytes(1, 0, 1, 1, 1, 7, 0) == 0
 
 
 def test_bad_arguments_are_rejected_before_any_device_work():
@@ -66,5 +67,11 @@ def test_bad_arguments_are_rejected_before_any_device_work():
     o.stop_rule = 0
     assert args(o, M=0) == -1
     assert args(o, T=0) == 0               # nothing to do is not an error
+    o.iters = 5; o.eps_mode = 0
+    conv = lambda H, Mb: L.evc_nmf_convert(one, 25, one, 25, one, 25, H, 64, one, 25, 25, Mb, 64, 10, None, 1,
+                                           C.byref(o), one, 1 << 30, None, None, None)
+    assert conv(one, 0) == -1              # Mb < 1
+    o.init_mode = _lib.INIT_GIVEN
+    assert conv(None, 25) == -1            # H0 must be given when init is GIVEN
     assert L.evc_synthesize(one, 1, one, 64, one, 25, 25, 64, 10, 0, 0, None) == -1   # ldb < Mb
     assert L.evc_synthesize(one, 25, one, 64, one, 25, 25, 64, 0, 0, 0, None) == 0

@@ -180,6 +180,30 @@ def test_modes_and_layouts(M, N, T, eps_mode, eps, layout):
         assert_close64(got, want, f"{algo} {eps_mode} {layout}")
 
 
+@pytest.mark.parametrize("M,Mb,N,T", [(25, 25, 256, 70), (25, 7, 130, 33), (20, 40, 128, 50), (201, 25, 96, 40)])
+@pytest.mark.parametrize("layout", ["bin_major", "frame_major"])
+def test_convert_is_solve_then_synthesize(M, Mb, N, T, layout):
+    """evc_nmf_convert (factorize()+convert() in one call) on the fused path (synthesis from the packed
+    tiles, Mb <= 32), with a wide target dictionary (Mb > 32) and on the generic path (M > 32)."""
+    import exemplars_vc_amd as evc
+    o = oracle()
+    p = o.synth_problem(M, N, T, Mb=Mb, seed=M + Mb)
+    H0 = np.random.default_rng(3).random((N, T)) + 1e-4
+    Hw = o.mu_solve(p["A"], p["X"], H0, 30, eps_mode=o.EPS_ADD, eps=1e-9)
+    Yw = p["B"] @ Hw
+    tr = (lambda a: a) if layout == "bin_major" else (lambda a: np.ascontiguousarray(a.T))
+    H, Y, info = evc.convert(tr(p["A"]), tr(p["X"]), tr(p["B"]), tr(H0), layout=layout, iters=30, info=True)
+    assert_close64(tr(H) if layout == "frame_major" else H, Hw, "H")
+    assert_close64(tr(Y) if layout == "frame_major" else Y, Yw, "Y")
+    assert int(info["n_iter"][0]) == 30
+    # Y alone: the activations never leave the solver (constant init, since H0 cannot be passed)
+    Hc = evc.solve_activations(tr(p["A"]), tr(p["X"]), layout=layout, iters=12, init="const", init_value=0.02)
+    Yc = evc.convert(tr(p["A"]), tr(p["X"]), tr(p["B"]), want_h=False, layout=layout, iters=12, init="const",
+                     init_value=0.02)
+    want = p["B"] @ (Hc if layout == "bin_major" else Hc.T)
+    assert_close64(Yc if layout == "bin_major" else Yc.T, want, "Y only")
+
+
 def test_strided_device_tensors_and_zero_iterations():
     import torch
     import exemplars_vc_amd as evc
@@ -252,9 +276,10 @@ def test_c2_full_size_properties():
     o = oracle()
     M, N, T, K = 25, 4096, 2048, 100
     p = o.synth_problem(M, N, T, seed=20190131)
-    H = evc.solve_activations(p["A"], p["X"], iters=K, eps_mode="zero_replace", init="sklearn",
-                              utt_offsets=[0, 688, 1376, T])
+    H, Y = evc.convert(p["A"], p["X"], p["B"], iters=K, eps_mode="zero_replace", init="sklearn",
+                       utt_offsets=[0, 688, 1376, T])
     assert (H >= 0).all() and np.isfinite(H).all()
+    assert_close64(Y, p["B"] @ H, "Y = B H at full size", rtol=1e-10)
     # frames 0..687 form utterance 0: identical to solving that utterance alone
     H0 = evc.solve_activations(p["A"], p["X"][:, :688], iters=K, eps_mode="zero_replace", init="sklearn")
     assert np.array_equal(H[:, :688], H0)
