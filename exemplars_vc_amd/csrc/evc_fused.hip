@@ -30,21 +30,24 @@ namespace evc {
 // ------------------------------------------------------------------------------------------
 // packing (runs once per call)
 // ------------------------------------------------------------------------------------------
-// A1p[j][s][l] = A[bin_of(s, l>>4)][16 j + 4 (l&3) + ((l&15)>>2)]   (A-operand of D and P)
-// A2p[j][u][r][l] = A[16 u + (l&15)][16 j + 4 (l>>4) + r]           (A-operand of V')
+// Dictionary fragments, two consecutive k-steps per lane side by side (one 16-byte load per pair):
+// A1p[j][s/2][l][s&1]      = A[bin_of(s, l>>4)][16 j + 4 (l&3) + ((l&15)>>2)]   (A-operand of D and P;
+//                            s padded to an even count, the pad is zero)
+// A2p[j][u][r/2][l][r&1]   = A[16 u + (l&15)][16 j + 4 (l>>4) + r]              (A-operand of V')
 __global__ void k_pack_dict(const double* __restrict__ At, int ldA, int NT, int msteps, int mtiles,
                             double* __restrict__ A1p, double* __restrict__ A2p) {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long n1 = (long)NT * msteps * 64, n2 = (long)NT * mtiles * 4 * 64;
+    const int msp = (msteps + 1) & ~1;
+    const long n1 = (long)NT * msp * 64, n2 = (long)NT * mtiles * 4 * 64;
     if (gid < n1) {
-        const int l = gid & 63, s = (gid >> 6) % msteps;
-        const long j = (gid >> 6) / msteps;
+        const int e = gid & 1, l = (gid >> 1) & 63, s = 2 * (int)((gid >> 7) % (msp / 2)) + e;
+        const long j = (gid >> 7) / (msp / 2);
         const int i = l & 15;
         const long n = 16 * j + 4 * (i & 3) + (i >> 2);
-        A1p[gid] = At[n * ldA + bin_of(s, l >> 4)];
+        A1p[gid] = s < msteps ? At[n * ldA + bin_of(s, l >> 4)] : 0.0;
     } else if (gid < n1 + n2) {
         const long g = gid - n1;
-        const int l = g & 63, r = (g >> 6) & 3, u = (g >> 8) % mtiles;
+        const int e = g & 1, l = (g >> 1) & 63, r = 2 * (int)((g >> 7) & 1) + e, u = (g >> 8) % mtiles;
         const long j = (g >> 8) / mtiles;
         const long n = 16 * j + 4 * (l >> 4) + r;
         A2p[g] = At[n * ldA + 16 * u + (l & 15)];
@@ -163,6 +166,7 @@ template <int MSTEPS, int C> struct TileRegs {
 template <int MSTEPS, int C, int NW, bool PF, int DBG = 0>
 __global__ __launch_bounds__(NW * 64) void k_fused_mu(FusedArgs a) {
     constexpr int MT = MSTEPS > 4 ? 2 : 1;
+    constexpr int MSP = (MSTEPS + 1) & ~1;       // k-steps padded to pairs in A1p
     constexpr int E = C * MT * 4 * 64;           // doubles in one V (accumulator order)
     extern __shared__ double lds[];
     double* red = lds;                           // [NW][E]   partial V' of every wavefront
@@ -208,12 +212,20 @@ __global__ __launch_bounds__(NW * 64) void k_fused_mu(FusedArgs a) {
         const int ja = (DBG & 2) ? w : j;
         if (with_a1) {
 #pragma unroll
-            for (int s = 0; s < MSTEPS; ++s) R.a1[s] = A1p[((long)ja * MSTEPS + s) * 64 + lane];
+            for (int s = 0; s < MSTEPS; s += 2) {
+                const f64x2 v = reinterpret_cast<const f64x2*>(A1p)[((long)ja * (MSP / 2) + (s >> 1)) * 64 + lane];
+                R.a1[s] = v[0];
+                if (s + 1 < MSTEPS) R.a1[s + 1] = v[1];
+            }
         }
 #pragma unroll
         for (int u = 0; u < MT; ++u)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) R.a2[u][r] = A2p[(((long)ja * MT + u) * 4 + r) * 64 + lane];
+            for (int r = 0; r < 4; r += 2) {
+                const f64x2 v = reinterpret_cast<const f64x2*>(A2p)[(((long)ja * MT + u) * 2 + (r >> 1)) * 64 + lane];
+                R.a2[u][r] = v[0];
+                R.a2[u][r + 1] = v[1];
+            }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             if (DBG & 1) { R.h01[c] = f64x2{1e-3, 2e-3}; R.h23[c] = f64x2{1e-3, 3e-3}; continue; }
@@ -393,7 +405,7 @@ FusedLayout fused_layout(int M, int N, int T_) {
     f.NT = (N + 15) / 16;
     f.TT = (T_ + 15) / 16;
     f.TTp = round_up(f.TT, 4);
-    f.a1 = (size_t)f.NT * f.msteps * 64;
+    f.a1 = (size_t)f.NT * ((f.msteps + 1) & ~1) * 64;
     f.a2 = (size_t)f.NT * f.mtiles * 4 * 64;
     f.xp = (size_t)f.TTp * f.msteps * 64;
     f.hp = (size_t)f.TTp * f.NT * 256;

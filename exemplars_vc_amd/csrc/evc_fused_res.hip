@@ -27,12 +27,15 @@
 #ifndef EVC_RES_MAX
 #define EVC_RES_MAX 16
 #endif
+#ifndef EVC_RES_PL
+#define EVC_RES_PL 7      // numerator tiles per wavefront cached in LDS (8 x 7 x 2 KiB = 112 KiB)
+#endif
 
 namespace evc {
 
 constexpr int RNW = 8;    // wavefronts per workgroup
 
-template <int MSTEPS, int RES>
+template <int MSTEPS, int RES, int PL>
 __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
     constexpr int MT = MSTEPS > 4 ? 2 : 1;
     constexpr int E = MT * 4 * 64;               // doubles in one V (accumulator order)
@@ -40,6 +43,9 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
     double* red = lds;                           // [RNW][E]  partial V' of every wavefront
     double* vL = lds + RNW * E;                  // [MT*4][64]  V, B-operand order
     double* xL = vL + E;                         // [MT*4][64]  X, B-operand order
+    // numerator tiles P = A_j^T X of the first PL tiles of every wavefront: computed in the first sweep
+    // of a launch, read back afterwards (7 fewer MFMAs per unit; LDS would otherwise sit idle)
+    f64x2* pL = reinterpret_cast<f64x2*>(xL + E) + (size_t)(threadIdx.x >> 6) * (PL * 128);   // [PL][2][64] per wavefront
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long tt = blockIdx.x;
@@ -73,20 +79,29 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
     // the iteration loop into SGPRs that then spill.
     const unsigned ul = (unsigned)lane;
     long sw = 0;
-    const long a1w = (long)w * MSTEPS * 64;                           // tile k: + k * RNW*MSTEPS*64
+    constexpr int MSP = (MSTEPS + 1) & ~1;                            // k-steps padded to pairs in A1p
+    const long a1w = (long)w * MSP * 64;                              // tile k: + k * RNW*MSP*64
     const long a2w = (long)w * MT * 256;                              // tile k: + k * RNW*MT*256
     const long hw = (tt * NT + w) * 128;                              // tile k: + k * RNW*128
     auto load_a1 = [&](double (&a1)[MSTEPS], int k) {
-        const double* t = A1p + (a1w + sw + (long)k * (RNW * MSTEPS * 64));
+        const f64x2* t = reinterpret_cast<const f64x2*>(A1p + (a1w + sw + (long)k * (RNW * MSP * 64)));
 #pragma unroll
-        for (int s = 0; s < MSTEPS; ++s) a1[s] = t[s * 64 + ul];
+        for (int s = 0; s < MSTEPS; s += 2) {
+            const f64x2 v = t[(s >> 1) * 64 + ul];
+            a1[s] = v[0];
+            if (s + 1 < MSTEPS) a1[s + 1] = v[1];
+        }
     };
     auto load_a2 = [&](double (&a2)[MT][4], int k) {
-        const double* t = A2p + (a2w + sw + (long)k * (RNW * MT * 256));
+        const f64x2* t = reinterpret_cast<const f64x2*>(A2p + (a2w + sw + (long)k * (RNW * MT * 256)));
 #pragma unroll
         for (int u = 0; u < MT; ++u)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) a2[u][r] = t[(u * 4 + r) * 64 + ul];
+            for (int r = 0; r < 4; r += 2) {
+                const f64x2 v = t[(u * 2 + (r >> 1)) * 64 + ul];
+                a2[u][r] = v[0];
+                a2[u][r + 1] = v[1];
+            }
     };
     auto load_h = [&](double (&h)[4], int k) {
         const f64x2* t = Hp + (hw + sw + (long)k * (RNW * 128));
@@ -113,16 +128,32 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
     const unsigned lo = fast_lo(mode, eps);
 
     // one unit: D = A_j^T V (+l1), P = A_j^T X, h <- h * P / D, V' += A_j h
+    int it = 0;
+    // D (and P, unless tile k's numerator is cached in LDS: k < PL and not the first sweep)
+    auto dp = [&](const double (&a1)[MSTEPS], f64x4& d, f64x4& p, int k) {
+        if (k < PL && it > 0) {
+#pragma unroll
+            for (int s = 0; s < MSTEPS; ++s) d = Mma<double>::mma(a1[s], vL[s * 64 + lane], d);
+            const f64x2 p01 = pL[(k * 2) * 64 + lane], p23 = pL[(k * 2 + 1) * 64 + lane];
+            p = f64x4{p01[0], p01[1], p23[0], p23[1]};
+        } else {
+#pragma unroll
+            for (int s = 0; s < MSTEPS; ++s) {
+                d = Mma<double>::mma(a1[s], vL[s * 64 + lane], d);
+                p = Mma<double>::mma(a1[s], xL[s * 64 + lane], p);
+            }
+            if (k < PL) {
+                pL[(k * 2) * 64 + lane] = f64x2{p[0], p[1]};
+                pL[(k * 2 + 1) * 64 + lane] = f64x2{p[2], p[3]};
+            }
+        }
+    };
     auto unit = [&](double (&a1)[MSTEPS], double (&a2)[MT][4], double (&h)[4], f64x4 (&vn)[MT], int k,
                     bool more) {
         __builtin_amdgcn_sched_barrier(0);       // keep the unrolled units' loads where they are written
         load_a2(a2, k);
         f64x4 d = dinit, p = {0, 0, 0, 0};
-#pragma unroll
-        for (int s = 0; s < MSTEPS; ++s) {
-            d = Mma<double>::mma(a1[s], vL[s * 64 + lane], d);
-            p = Mma<double>::mma(a1[s], xL[s * 64 + lane], p);
-        }
+        dp(a1, d, p, k);
         if (more) load_a1(a1, k + 1);            // operand registers are free once the MFMAs issued
         __builtin_amdgcn_sched_barrier(0);
         mu_tile<false>(h, p, d, mode, eps, lo);
@@ -134,7 +165,7 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
 
     double a1[MSTEPS], a2[MT][4];
     double hs[2][4];
-    for (int it = 0; it < a.iters; ++it) {
+    for (it = 0; it < a.iters; ++it) {
         // opaque to the optimiser: the per-tile addresses are re-derived with scalar adds in every
         // sweep instead of being hoisted out of this loop into ~200 SGPRs (which then spill)
         asm volatile("" : "+s"(sw));
@@ -156,11 +187,7 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
             load_a2(a2, 2 * k2 + 1);
             {
                 f64x4 d = dinit, p = {0, 0, 0, 0};
-#pragma unroll
-                for (int s = 0; s < MSTEPS; ++s) {
-                    d = Mma<double>::mma(a1[s], vL[s * 64 + lane], d);
-                    p = Mma<double>::mma(a1[s], xL[s * 64 + lane], p);
-                }
+                dp(a1, d, p, 2 * k2 + 1);
                 if (more) load_a1(a1, 2 * k2 + 2);
                 if (k2 + 1 < RES) load_h(hs[(k2 + 1) & 1], 2 * k2 + 3);
                 __builtin_amdgcn_sched_barrier(0);
@@ -222,8 +249,14 @@ template <int MSTEPS, int RES>
 static hipError_t launch_res(const FusedArgs& a, hipStream_t s) {
     constexpr int MT = MSTEPS > 4 ? 2 : 1;
     constexpr int E = MT * 4 * 64;
-    const size_t lds = (size_t)(RNW + 2) * E * sizeof(double);
-    hipLaunchKernelGGL((k_fused_res<MSTEPS, RES>), dim3((unsigned)a.TT), dim3(RNW * 64), lds, s, a);
+    constexpr int PL = EVC_RES_PL;
+    const size_t lds = (size_t)(RNW + 2) * E * sizeof(double) + (size_t)RNW * PL * 256 * sizeof(double);
+    if (lds > 64 * 1024) {   // per launch: no mutable global state is kept
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_res<MSTEPS, RES, PL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_fused_res<MSTEPS, RES, PL>), dim3((unsigned)a.TT), dim3(RNW * 64), lds, s, a);
     return hipGetLastError();
 }
 
