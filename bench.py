@@ -188,6 +188,16 @@ def main():
         achieved = fl_loop / loop_s / 1e12
         peak = PEAK_F64_TFLOPS if args.dtype == "f64" else PEAK_F32_TFLOPS
         fused = args.algo == "factored" and args.dtype == "f64" and M <= 32 and not args.no_fused
+        # HBM bytes per launch from the committed PMC passes of this very workload (rocprofv3 cannot
+        # run inside the timed process); null when the profile on file is for another workload
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_bench_c2.json")))
+            wl = pm["workload"]
+            if fused and (wl["M"], wl["N"], wl["K"], wl["frames"], wl["dtype"]) == (M, N, K, T, args.dtype):
+                traffic = pm["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         res = {
             "metric": "spectral frames/sec converted (100 NMF iters, N=4096 dict)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
@@ -202,7 +212,7 @@ def main():
                        "frames_per_gpu": T, "parallelism": f"utterance shards x{world}"},
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                "frac": achieved / peak, "traffic": None,
+                "frac": achieved / peak, "traffic": traffic,
                 "kernel": "iteration loop (k_fused_res)" if fused else "iteration loop (k_gemm_nt family)",
                 "launch_ms": 1e3 * loop_s,
                 "algorithmic_flops_per_launch": fl_loop,

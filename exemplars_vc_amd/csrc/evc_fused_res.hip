@@ -105,13 +105,22 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
     };
     auto load_h = [&](double (&h)[4], int k) {
         const f64x2* t = Hp + (hw + sw + (long)k * (RNW * 128));
+#ifdef EVC_RES_NT
+        const f64x2 h01 = __builtin_nontemporal_load(&t[ul]), h23 = __builtin_nontemporal_load(&t[ul + 64]);
+#else
         const f64x2 h01 = t[ul], h23 = t[ul + 64];
+#endif
         h[0] = h01[0]; h[1] = h01[1]; h[2] = h23[0]; h[3] = h23[1];
     };
     auto store_h = [&](const double (&h)[4], int k) {
         f64x2* t = Hp + (hw + sw + (long)k * (RNW * 128));
+#ifdef EVC_RES_NT
+        __builtin_nontemporal_store(f64x2{h[0], h[1]}, &t[ul]);
+        __builtin_nontemporal_store(f64x2{h[2], h[3]}, &t[ul + 64]);
+#else
         t[ul] = f64x2{h[0], h[1]};
         t[ul + 64] = f64x2{h[2], h[3]};
+#endif
     };
     auto vacc = [&](const double (&a2)[MT][4], const double (&h)[4], f64x4 (&vn)[MT]) {
 #pragma unroll
