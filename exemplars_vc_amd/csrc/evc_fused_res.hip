@@ -198,10 +198,12 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
                 f64x4 d = dinit, p = {0, 0, 0, 0};
                 dp(a1, d, p, 2 * k2 + 1);
                 if (more) load_a1(a1, 2 * k2 + 2);
-                if (k2 + 1 < RES) load_h(hs[(k2 + 1) & 1], 2 * k2 + 3);
                 __builtin_amdgcn_sched_barrier(0);
                 mu_tile<false>(hs[k2 & 1], p, d, mode, eps, lo);
             }
+            // the next streamed tile's load goes out here, two units ahead of its use (after the update:
+            // registers with a load in flight must not cross the update's rare-path merge)
+            if (k2 + 1 < RES) load_h(hs[(k2 + 1) & 1], 2 * k2 + 3);
             store_h(hs[k2 & 1], 2 * k2 + 1);
             vacc(a2, hs[k2 & 1], vn);
         }
