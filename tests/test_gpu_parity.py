@@ -204,6 +204,63 @@ def test_convert_is_solve_then_synthesize(M, Mb, N, T, layout):
     assert_close64(Yc if layout == "bin_major" else Yc.T, want, "Y only")
 
 
+@pytest.mark.parametrize("N", [1024, 2048, 4096, 1152])
+@pytest.mark.parametrize("eps_mode,eps,l1", [("add", 1e-9, 0.0), ("zero_replace", 1.1920929e-7, 0.0),
+                                              ("clamp", 1e-15, 0.0), ("zero_replace", 1.1920929e-7, 0.3)])
+def test_register_resident_kernel_modes(N, eps_mode, eps, l1):
+    """k_fused_res runs for N % 128 == 0, N >= 1024 (4, 8 or 16 resident tiles per wavefront; N = 1152 has
+    a streamed tail beyond the resident window).  Every guarded mode, ragged T (padded frames), zero
+    frames (exact path of the update) and an absorbing zero row, against the oracle."""
+    import exemplars_vc_amd as evc
+    o = oracle()
+    M, T, K = 25, 37, 25
+    p = o.synth_problem(M, N, T, seed=N)
+    X = p["X"].copy()
+    X[:, 5] = 0.0
+    H0 = np.random.default_rng(N).random((N, T)) + 1e-4
+    H0[17, :] = 0.0
+    code = {"add": o.EPS_ADD, "zero_replace": o.EPS_ZERO_REPLACE, "clamp": o.EPS_CLAMP}[eps_mode]
+    want = o.mu_solve(p["A"], X, H0, K, eps_mode=code, eps=eps, l1=l1, algo="gram")
+    got = evc.solve_activations(p["A"], X, H0, iters=K, eps_mode=eps_mode, eps=eps, l1=l1)
+    assert_close64(got, want, f"resident N={N} {eps_mode}")
+    assert (got[17] == 0).all() and (got[:, 5] == 0).all()
+    gen = evc.solve_activations(p["A"], X, H0, iters=K, eps_mode=eps_mode, eps=eps, l1=l1, fused_c=1)
+    assert_close64(gen, want, f"general N={N} {eps_mode}")
+
+
+@pytest.mark.parametrize("N", [1024, 4096])
+def test_register_resident_kernel_with_stop_rules(N):
+    """Stopping rules at a size where the resident kernel is in charge: utterances stop at different
+    iterations, so some workgroups (16 frames) hold frozen and live frames at once and are handed to
+    the general kernel (skip_all_live), including a workgroup straddling two utterances."""
+    from exemplars_vc_amd.compat.factorize import factorize_utterances
+    o = oracle()
+    p = o.synth_problem(25, N, 0, seed=N + 1)
+    W = np.ascontiguousarray(p["A"].T)
+
+    def make(kind, T):      # four kinds of utterance that converge at different speeds
+        rng = np.random.default_rng(N + kind)
+        if kind == 0:
+            Hs = rng.random((N, T)) * (rng.random((N, T)) < 3.0 / N)
+            return np.ascontiguousarray((p["A"] @ Hs + 1e-6).T)
+        if kind == 1:
+            return rng.random((T, 25)) ** 4 + 1e-3
+        if kind == 2:
+            return np.ascontiguousarray(p["A"][:, rng.integers(0, N, T)].T * 3.0)
+        return np.ascontiguousarray((p["A"] @ rng.random((N, T))).T)
+
+    Xs = [make(0, 40), make(1, 9), make(2, 70), make(3, 23)]
+    tol = 3e-3
+    Hs_gpu, n_iter = factorize_utterances(Xs, W, tol=tol, max_iter=60)
+    want_iters = []
+    for X, Hg, ni in zip(Xs, Hs_gpu, n_iter):
+        act, n, _ = o.sklearn_mu_fixed_dictionary(X, W, 60, tol)
+        want_iters.append(n)
+        assert n == ni, (n, ni)
+        assert_close64(Hg, act.T, "H")
+    assert len(set(want_iters)) > 2, want_iters
+
+
 def test_strided_device_tensors_and_zero_iterations():
     import torch
     import exemplars_vc_amd as evc
