@@ -156,7 +156,7 @@ int solve_fused(const Workspace<T>& w, const Dims& d, const evc_solve_opts& o, i
 template <>
 int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_solve_opts& o, int n_utt,
                         hipStream_t s) {
-    const int c_override = (o.reserved >> 8) & 0xffff;   // C | variant << 8
+    const int c_override = (o.reserved >> 8) & 0xff;     // 0 = automatic, 1 / 2 = general kernel
     HIP_TRY(fused_pack_dict(w.fl, w.fb.A1p, w.fb.A2p, w.At, d.Mk, s));
     HIP_TRY(fused_pack_frames(w.fl, w.fb.Xp, w.Xt, d.Mk, s));
     int first = 1;

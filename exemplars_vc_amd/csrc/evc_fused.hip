@@ -64,19 +64,8 @@ __global__ void k_pack_frames(const double* __restrict__ Xt, int ldx, long TTp, 
     Xp[gid] = Xt[(16 * tt + (l & 15)) * ldx + bin_of(s, l >> 4)];
 }
 
-// Hp[tt][j][p][l] (2 doubles) = H[16 j + 4 (l>>4) + 2p + {0,1}][16 tt + (l&15)]
-template <bool PACK>
-__global__ void k_pack_h(double* __restrict__ Ht, int ldh, long TTp, int NT, f64x2* __restrict__ Hp) {
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= TTp * NT * 128) return;
-    const int l = gid & 63, p = (gid >> 6) & 1;
-    const long tile = gid >> 7;
-    const long j = tile % NT, tt = tile / NT;
-    double* src = Ht + (16 * tt + (l & 15)) * ldh + 16 * j + 4 * (l >> 4) + 2 * p;
-    if (PACK) Hp[gid] = *reinterpret_cast<const f64x2*>(src);
-    else *reinterpret_cast<f64x2*>(src) = Hp[gid];
-}
-
+// Hp[tt][j][p][l] (2 doubles) = H[16 j + 4 (l>>4) + 2p + {0,1}][16 tt + (l&15)]: the activation tiles,
+// in accumulator order.
 // Hp <-> the caller's H (either layout, any strides): one wavefront per 16x16 tile, staged through
 // a wave-private LDS tile so that the caller-side accesses are whole 128-byte rows.  Out-of-range
 // frames / exemplars read as 0 and are not written.
@@ -153,8 +142,7 @@ __global__ __launch_bounds__(256) void k_unpack_y(const double* __restrict__ Yp,
 }
 
 // Registers of one 16-exemplar dictionary tile (both operand orders) and of the C activation
-// tiles that go with it; two of these ping-pong so that tile j+NW is in flight while tile j is
-// on the matrix cores.
+// tiles that go with it.
 template <int MSTEPS, int C> struct TileRegs {
     static constexpr int MT = MSTEPS > 4 ? 2 : 1;
     double a1[MSTEPS];
@@ -162,8 +150,9 @@ template <int MSTEPS, int C> struct TileRegs {
     f64x2 h01[C], h23[C];
 };
 
-// DBG (timing experiments only, results are wrong): bit 0 = no H traffic, bit 1 = no dictionary loads
-template <int MSTEPS, int C, int NW, bool PF, int DBG = 0>
+constexpr int NW = 8;   // wavefronts per workgroup
+
+template <int MSTEPS, int C>
 __global__ __launch_bounds__(NW * 64) void k_fused_mu(FusedArgs a) {
     constexpr int MT = MSTEPS > 4 ? 2 : 1;
     constexpr int MSP = (MSTEPS + 1) & ~1;       // k-steps padded to pairs in A1p
@@ -209,11 +198,10 @@ __global__ __launch_bounds__(NW * 64) void k_fused_mu(FusedArgs a) {
 
     typedef TileRegs<MSTEPS, C> Regs;
     auto load_tile = [&](Regs& R, int j, bool with_a1) {
-        const int ja = (DBG & 2) ? w : j;
         if (with_a1) {
 #pragma unroll
             for (int s = 0; s < MSTEPS; s += 2) {
-                const f64x2 v = reinterpret_cast<const f64x2*>(A1p)[((long)ja * (MSP / 2) + (s >> 1)) * 64 + lane];
+                const f64x2 v = reinterpret_cast<const f64x2*>(A1p)[((long)j * (MSP / 2) + (s >> 1)) * 64 + lane];
                 R.a1[s] = v[0];
                 if (s + 1 < MSTEPS) R.a1[s + 1] = v[1];
             }
@@ -222,17 +210,16 @@ __global__ __launch_bounds__(NW * 64) void k_fused_mu(FusedArgs a) {
         for (int u = 0; u < MT; ++u)
 #pragma unroll
             for (int r = 0; r < 4; r += 2) {
-                const f64x2 v = reinterpret_cast<const f64x2*>(A2p)[(((long)ja * MT + u) * 2 + (r >> 1)) * 64 + lane];
+                const f64x2 v = reinterpret_cast<const f64x2*>(A2p)[(((long)j * MT + u) * 2 + (r >> 1)) * 64 + lane];
                 R.a2[u][r] = v[0];
                 R.a2[u][r + 1] = v[1];
             }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            if (DBG & 1) { R.h01[c] = f64x2{1e-3, 2e-3}; R.h23[c] = f64x2{1e-3, 3e-3}; continue; }
             if (tt0 + c >= a.TT) { R.h01[c] = f64x2{0, 0}; R.h23[c] = f64x2{0, 0}; continue; }
             const long hb = ((tt0 + c) * NT + j) * 128 + lane;
-            if (DBG & 8) { R.h01[c] = __builtin_nontemporal_load(&Hp[hb]); R.h23[c] = __builtin_nontemporal_load(&Hp[hb + 64]); }
-            else { R.h01[c] = Hp[hb]; R.h23[c] = Hp[hb + 64]; }
+            R.h01[c] = Hp[hb];
+            R.h23[c] = Hp[hb + 64];
         }
     };
 
@@ -297,8 +284,9 @@ __global__ __launch_bounds__(NW * 64) void k_fused_mu(FusedArgs a) {
             for (int c = 0; c < C; ++c)
 #pragma unroll
                 for (int u = 0; u < MT; ++u) vn[c][u] = f64x4{0, 0, 0, 0};
-
-            auto compute_tile = [&](const Regs& R, int j) {
+            for (int j = w; j < NT; j += NW) {
+                Regs R;
+                load_tile(R, j, true);
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     if (MASKED && tt0 + c >= a.TT) continue;     // uniform
@@ -309,10 +297,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused_mu(FusedArgs a) {
                         p = Mma<double>::mma(R.a1[s], xL[(c * MT * 4 + s) * 64 + lane], p);
                     }
                     double h[4] = {R.h01[c][0], R.h01[c][1], R.h23[c][0], R.h23[c][1]};
-                    if (DBG & 4) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) h[r] = h[r] * p[r] + d[r];
-                    } else if (MASKED) {
+                    if (MASKED) {
                         double hn[4] = {h[0], h[1], h[2], h[3]};
                         mu_tile<MUL_FIRST>(hn, p, d, mode, eps, lo);
                         const int n0 = 16 * j + 4 * q;
@@ -325,38 +310,12 @@ __global__ __launch_bounds__(NW * 64) void k_fused_mu(FusedArgs a) {
                         mu_tile<MUL_FIRST>(h, p, d, mode, eps, lo);
                     }
                     const long hb = ((tt0 + c) * NT + j) * 128 + lane;
-                    if (DBG & 8) {
-                        __builtin_nontemporal_store(f64x2{h[0], h[1]}, &Hp[hb]);
-                        __builtin_nontemporal_store(f64x2{h[2], h[3]}, &Hp[hb + 64]);
-                    } else if (!(DBG & 1) || h[0] == 123.456) {
-                        Hp[hb] = f64x2{h[0], h[1]};
-                        Hp[hb + 64] = f64x2{h[2], h[3]};
-                    }
+                    Hp[hb] = f64x2{h[0], h[1]};
+                    Hp[hb + 64] = f64x2{h[2], h[3]};
 #pragma unroll
                     for (int u = 0; u < MT; ++u)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) vn[c][u] = Mma<double>::mma(R.a2[u][r], h[r], vn[c][u]);
-                }
-            };
-
-            if (PF) {
-                Regs R0, R1;
-                int j = w;
-                if (j < NT) load_tile(R0, j, true);
-                for (; j < NT; j += 2 * NW) {
-                    const int j1 = j + NW, j2 = j + 2 * NW;
-                    if (j1 < NT) load_tile(R1, j1, true);
-                    compute_tile(R0, j);
-                    if (j1 < NT) {
-                        if (j2 < NT) load_tile(R0, j2, true);
-                        compute_tile(R1, j1);
-                    }
-                }
-            } else {
-                for (int j = w; j < NT; j += NW) {
-                    Regs R;
-                    load_tile(R, j, true);
-                    compute_tile(R, j);
                 }
             }
             reduce_v(vn);
@@ -451,85 +410,66 @@ hipError_t fused_fill_h(const FusedLayout& f, double* Hp, int N, int T_, const U
     return hipGetLastError();
 }
 
-template <int MSTEPS, int C, int NW, bool PF, int DBG = 0>
+template <int MSTEPS, int C>
 static hipError_t launch_fused(const FusedArgs& a, hipStream_t s) {
     constexpr int MT = MSTEPS > 4 ? 2 : 1;
     constexpr int E = C * MT * 4 * 64;
     const size_t lds = (size_t)(NW + 2) * E * sizeof(double);
     const unsigned grid = (unsigned)((a.TT + C - 1) / C);
     if (lds > 48 * 1024) {   // per-launch, so that no mutable global state is kept
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_mu<MSTEPS, C, NW, PF, DBG>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_mu<MSTEPS, C>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_fused_mu<MSTEPS, C, NW, PF, DBG>), dim3(grid), dim3(NW * 64), lds, s, a);
+    hipLaunchKernelGGL((k_fused_mu<MSTEPS, C>), dim3(grid), dim3(NW * 64), lds, s, a);
     return hipGetLastError();
 }
 
-template <int C, int NW, bool PF>
+template <int C>
 static hipError_t dispatch_msteps(int msteps, const FusedArgs& a, hipStream_t s) {
     switch (msteps) {
-        case 1: return launch_fused<1, C, NW, PF>(a, s);
-        case 2: return launch_fused<2, C, NW, PF>(a, s);
-        case 3: return launch_fused<3, C, NW, PF>(a, s);
-        case 4: return launch_fused<4, C, NW, PF>(a, s);
-        case 5: return launch_fused<5, C, NW, PF>(a, s);
-        case 6: return launch_fused<6, C, NW, PF>(a, s);
-        case 7: return launch_fused<7, C, NW, PF>(a, s);
-        case 8: return launch_fused<8, C, NW, PF>(a, s);
+        case 1: return launch_fused<1, C>(a, s);
+        case 2: return launch_fused<2, C>(a, s);
+        case 3: return launch_fused<3, C>(a, s);
+        case 4: return launch_fused<4, C>(a, s);
+        case 5: return launch_fused<5, C>(a, s);
+        case 6: return launch_fused<6, C>(a, s);
+        case 7: return launch_fused<7, C>(a, s);
+        case 8: return launch_fused<8, C>(a, s);
         default: return hipErrorInvalidValue;
     }
 }
 
-int fused_pick_c(int T_) {
-    const int TT = (T_ + 15) / 16;
-    if (TT >= 1024) return 2;     // >= 512 workgroups of 32 frames: amortise the dictionary reads
-    return 1;                     // few frames: as many workgroups as possible
-}
-
-// variant: bits 0..7 frame tiles per workgroup (0 = automatic), bits 8..15 tuning variant id.
-// all_live_known: no stopping rule is in force, so every utterance is active for the whole call.
-static hipError_t launch_general(const FusedLayout& f, FusedArgs a, int T_, int variant, hipStream_t s) {
-    const int c_req = variant & 0xff, vid = (variant >> 8) & 0xff;
-    const int C = a.skip_all_live ? 1 : (c_req > 0 ? c_req : fused_pick_c(T_));
-    if (vid != 0 && f.msteps == 7 && !a.skip_all_live) {   // tuning variants exist for the C2 shape only
-        switch (vid * 10 + C) {
-            case 11: return launch_fused<7, 1, 8, true>(a, s);
-            case 21: return launch_fused<7, 1, 16, false>(a, s);
-            case 31: return launch_fused<7, 1, 4, false>(a, s);
-            case 32: return launch_fused<7, 2, 4, false>(a, s);
-            case 41: return launch_fused<7, 1, 8, false, 8>(a, s);     // nontemporal H accesses
-            case 51: return launch_fused<7, 1, 8, false, 1>(a, s);     // no H traffic
-            case 61: return launch_fused<7, 1, 8, false, 2>(a, s);     // no dictionary loads
-            case 71: return launch_fused<7, 1, 8, false, 3>(a, s);     // neither
-            case 81: return launch_fused<7, 1, 8, false, 7>(a, s);     // neither, no division
-            case 91: return launch_fused<7, 1, 8, false>(a, s);        // general kernel, as is
-            default: return hipErrorInvalidValue;
-        }
-    }
+// frame tiles (of 16) per workgroup of the general kernel: 2 amortise the dictionary reads when
+// there are plenty of workgroups, 1 otherwise (and always next to k_fused_res)
+static hipError_t launch_general(const FusedLayout& f, const FusedArgs& a, int c_req, hipStream_t s) {
+    const int C = a.skip_all_live ? 1 : (c_req > 0 ? c_req : (f.TT >= 1024 ? 2 : 1));
     switch (C) {
-        case 1: return dispatch_msteps<1, 8, false>(f.msteps, a, s);
-        case 2: return dispatch_msteps<2, 8, false>(f.msteps, a, s);
+        case 1: return dispatch_msteps<1>(f.msteps, a, s);
+        case 2: return dispatch_msteps<2>(f.msteps, a, s);
         default: return hipErrorInvalidValue;
     }
 }
 
+// c_req: 0 = automatic (k_fused_res where it applies), 1 / 2 = force the general kernel with that many
+// frame tiles per workgroup (tests, A/B timing).
+// all_live_known: no stopping rule is in force, so every utterance is active for the whole call.
 hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttState& u, int N, int T_,
                          int iters, int first, int write_err, double* err2, int eps_mode, double eps,
-                         double l1, int variant, int all_live_known, hipStream_t s) {
+                         double l1, int c_req, int all_live_known, hipStream_t s) {
     FusedArgs a;
     a.A1p = b.A1p; a.A2p = b.A2p; a.Xp = b.Xp; a.Hp = reinterpret_cast<f64x2*>(b.Hp); a.Vp = b.Vp;
     a.err2 = err2; a.frame_utt = u.frame_utt; a.active = u.active;
     a.NT = f.NT; a.TT = f.TT; a.N = N; a.T_ = T_;
     a.iters = iters; a.first = first; a.write_err = write_err; a.skip_all_live = 0; a.force_live = 0;
     a.eps_mode = eps_mode; a.eps = eps; a.l1 = l1;
-    const bool resident = variant == 0 && fused_res_supported(N, eps_mode);
-    if (!resident) return launch_general(f, a, T_, variant, s);
+    const bool resident = c_req == 0 && fused_res_supported(N, eps_mode);
+    if (!resident) return launch_general(f, a, c_req, s);
     if (first) {                 // V = A H (and the residual at init) by the general kernel's pre-pass
         FusedArgs p = a;
         p.iters = 0;
         p.write_err = (iters == 0) ? write_err : 0;
-        hipError_t e = launch_general(f, p, T_, 1, s);
+        hipError_t e = launch_general(f, p, 1, s);
         if (e != hipSuccess) return e;
         a.first = 0;
     }
@@ -537,7 +477,7 @@ hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttS
     hipError_t e = fused_res_launch(f.msteps, a, s);
     if (e != hipSuccess || all_live_known) return e;
     a.skip_all_live = 1;         // workgroups holding frames of stopped utterances
-    return launch_general(f, a, T_, 1, s);
+    return launch_general(f, a, 1, s);
 }
 
 // Y = B H straight from the packed activations: the V pre-pass with B's fragments in place of A's
@@ -552,7 +492,7 @@ hipError_t fused_synthesize(const FusedLayout& fB, const double* B2p, const doub
     a.NT = fB.NT; a.TT = fB.TT; a.N = N; a.T_ = T_;
     a.iters = 0; a.first = 1; a.write_err = 0; a.skip_all_live = 0; a.force_live = 1;
     a.eps_mode = EVC_EPS_ADD; a.eps = 0; a.l1 = 0;
-    hipError_t e = dispatch_msteps<1, 8, false>(fB.msteps, a, s);
+    hipError_t e = dispatch_msteps<1>(fB.msteps, a, s);
     if (e != hipSuccess) return e;
     const long n = (long)fB.TT * fB.msteps * 64;
     hipLaunchKernelGGL(k_unpack_y, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Yp, n, fB.msteps, Mb, T_,

@@ -148,6 +148,6 @@ hipError_t fused_synthesize(const FusedLayout& fB, const double* B2p, const doub
 // Vp from the previous launch); write_err: per-frame squared residuals of the final H -> err2.
 hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttState& u, int N, int T_,
                          int iters, int first, int write_err, double* err2, int eps_mode, double eps,
-                         double l1, int variant, int all_live_known, hipStream_t s);
+                         double l1, int c_req, int all_live_known, hipStream_t s);
 
 }  // namespace evc

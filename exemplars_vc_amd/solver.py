@@ -194,9 +194,9 @@ def _solve(A, X, H0, B, *, layout="bin_major", iters=100, eps_mode="add", eps=No
     opts.check_every, opts.stop_rule = int(check_every), _STOPS[stop_rule]
     opts.eps = _EPS_DEFAULT[eps_mode] if eps is None else float(eps)
     opts.l1, opts.tol, opts.init_value = float(l1), float(tol), float(init_value)
-    # tuning/testing knobs: bit 0 disables the fused persistent kernel, bits 8..15 force its
-    # frame-tiles-per-workgroup factor (0 = automatic)
-    opts.reserved = (0 if fused else 1) | ((int(fused_c) & 0xffff) << 8)
+    # testing knobs: bit 0 disables the fused persistent kernels; bits 8..15 = 1 or 2 force the
+    # general streamed kernel with that many frame tiles per workgroup (0 = automatic)
+    opts.reserved = (0 if fused else 1) | ((int(fused_c) & 0xff) << 8)
     if loop_events is not None:     # (torch.cuda.Event, torch.cuda.Event), already created
         opts.ev_loop_start = int(loop_events[0].cuda_event)
         opts.ev_loop_stop = int(loop_events[1].cuda_event)

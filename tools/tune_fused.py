@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Time the tuning variants of the fused kernel on the bench workload (GPU box only).
-usage: python tools/tune_fused.py [utterances] [variant ...]   variant = C + 256*vid"""
+usage: python tools/tune_fused.py [utterances] [c_req ...]   0 = k_fused_res, 1 or 2 = general kernel"""
 import sys, os, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import exemplars_vc_amd as evc
 
 U = int(sys.argv[1]) if len(sys.argv) > 1 else 96
-variants = [int(v) for v in sys.argv[2:]] or [1, 2, 257, 258, 513, 1025, 1026]
+variants = [int(v) for v in sys.argv[2:]] or [0, 1, 2]
 M, N, K, Tu = 25, 4096, 100, 688
 T = U * Tu
 dev = torch.device("cuda")
@@ -30,5 +30,5 @@ for rep in range(2):
         ms = e0.elapsed_time(e1)
         chk = float(H[:64].sum())
         if ref is None: ref = chk
-        print(f"rep{rep} variant C={v & 255} vid={v >> 8}: loop {ms:8.2f} ms  {T * 1e3 / ms / 1e3:9.1f} kframes/s  "
+        print(f"rep{rep} fused_c={v}: loop {ms:8.2f} ms  {T * 1e3 / ms / 1e3:9.1f} kframes/s  "
               f"checksum rel diff {abs(chk - ref) / abs(ref):.1e}", flush=True)
