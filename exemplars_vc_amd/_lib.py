@@ -18,6 +18,7 @@ EPS_ADD, EPS_ZERO_REPLACE, EPS_NONE, EPS_CLAMP = 0, 1, 2, 3
 ALGO_GRAM, ALGO_FACTORED, ALGO_LITERAL, ALGO_AUTO = 0, 1, 2, 3
 INIT_GIVEN, INIT_SKLEARN, INIT_CONST = 0, 1, 2
 STOP_NONE, STOP_SKLEARN, STOP_PYMF = 0, 1, 2
+LOSS_FROBENIUS, LOSS_KL = 0, 1
 
 # every symbol include/evc.h declares; tests check that the library exports all of them
 SYMBOLS = ("evc_version", "evc_strerror", "evc_device_count", "evc_workspace_bytes",
@@ -30,6 +31,7 @@ class SolveOpts(C.Structure):
         ("struct_bytes", C.c_int), ("dtype", C.c_int), ("layout", C.c_int), ("algo", C.c_int),
         ("iters", C.c_int), ("eps_mode", C.c_int), ("init_mode", C.c_int),
         ("check_every", C.c_int), ("stop_rule", C.c_int), ("reserved", C.c_int),
+        ("loss", C.c_int), ("reserved2", C.c_int),
         ("eps", C.c_double), ("l1", C.c_double), ("tol", C.c_double), ("init_value", C.c_double),
         ("ev_loop_start", C.c_void_p), ("ev_loop_stop", C.c_void_p),
     ]

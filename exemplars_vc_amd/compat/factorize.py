@@ -42,7 +42,8 @@ def _check_dictionary(W, n_features):
     return W
 
 
-def _factorize(X, W, beta_loss="kullback-leibler", tol=1e-4, *, device=None, algo="auto"):
+def _factorize(X, W, beta_loss="kullback-leibler", tol=1e-4, *, device=None, algo="auto",
+               honor_beta_loss=False):
     """H (N x T) with W.T @ H ~ X.T.  X: (T, M) frames as rows, W: (N, M) exemplars as rows.
 
     As in the reference the Frobenius loss is forced whatever `beta_loss` says, the
@@ -50,7 +51,11 @@ def _factorize(X, W, beta_loss="kullback-leibler", tol=1e-4, *, device=None, alg
     1.1920929e-7, and every 10 iterations the loop stops when the Frobenius error decreased by
     less than `tol` (relative to the initial error); at most 150 iterations.
     """
-    del beta_loss  # 04_align_n_nmf.py:210 overrides it with "frobenius"
+    # 04_align_n_nmf.py:210 overrides `beta_loss` with "frobenius" whatever the caller passed;
+    # honor_beta_loss=True runs the loss that was asked for (sklearn's KL update, SURVEY 8f-4)
+    loss = beta_loss if honor_beta_loss else "frobenius"
+    if loss not in ("frobenius", "kullback-leibler"):
+        raise ValueError(f"Invalid beta_loss parameter: got {loss!r}")
     X = np.asarray(X)
     if X.ndim != 2:
         raise ValueError(f"Expected 2D array, got {X.ndim}D array instead")
@@ -66,7 +71,7 @@ def _factorize(X, W, beta_loss="kullback-leibler", tol=1e-4, *, device=None, alg
     act, info = solve_activations(
         W, X, layout="frame_major", iters=MAX_ITER, eps_mode="zero_replace", init="sklearn",
         check_every=CHECK_EVERY if tol > 0 else 0, stop_rule="sklearn" if tol > 0 else "none",
-        tol=tol, algo=algo, device=device, info=True)
+        tol=tol, algo=algo, device=device, info=True, loss=loss)
     if tol > 0 and int(info["n_iter"][0]) == MAX_ITER:
         warnings.warn(f"Maximum number of iterations {MAX_ITER} reached. Increase it to improve "
                       "convergence.", ConvergenceWarning, stacklevel=2)

@@ -39,6 +39,7 @@ Dims make_dims(int M, int N, int T_, int n_utt, int Mb = 0) {
 
 template <typename T> struct Workspace {
     T *At, *Am, *Xt, *H0, *H1, *Pt, *G, *Vt;
+    T *Akl, *Rt;         // KL: dictionary / column sums, and X / max(V, eps)
     double* err2;
     UttState u;
     FusedLayout fl;
@@ -62,6 +63,8 @@ Workspace<T> carve(void* base, const Dims& d, int algo, int n_slots, bool fused)
     w.At = c.take<T>((size_t)d.Np * d.Mk);
     w.Am = c.take<T>((size_t)d.Mj * d.Np);
     w.Xt = c.take<T>((size_t)d.Tp * d.Mk);
+    w.Akl = c.take<T>((size_t)d.Np * d.Mk);
+    w.Rt = fused ? nullptr : c.take<T>((size_t)d.Tp * d.Mk);
     w.packed_synth = fused && d.Mb >= 1 && d.Mb <= 32;
     // the fused path keeps the activations in the packed layout only; a frames-as-rows copy is
     // needed by the generic path, and by a synthesis that cannot run from the packed tiles
@@ -157,12 +160,17 @@ template <>
 int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_solve_opts& o, int n_utt,
                         hipStream_t s) {
     const int c_override = (o.reserved >> 8) & 0xff;     // 0 = automatic, 1 / 2 = general kernel
-    HIP_TRY(fused_pack_dict(w.fl, w.fb.A1p, w.fb.A2p, w.At, d.Mk, s));
+    if (o.loss == EVC_LOSS_KL) {     // D/P operand order from the scaled dictionary, V' operand order from A
+        HIP_TRY(fused_pack_dict(w.fl, w.fb.A1p, nullptr, w.Akl, d.Mk, s));
+        HIP_TRY(fused_pack_dict(w.fl, nullptr, w.fb.A2p, w.At, d.Mk, s));
+    } else {
+        HIP_TRY(fused_pack_dict(w.fl, w.fb.A1p, w.fb.A2p, w.At, d.Mk, s));
+    }
     HIP_TRY(fused_pack_frames(w.fl, w.fb.Xp, w.Xt, d.Mk, s));
     int first = 1;
     if (o.check_every > 0 && o.stop_rule == EVC_STOP_SKLEARN) {   // error_at_init
         HIP_TRY(fused_iterate(w.fl, w.fb, w.u, d.N, d.T_, 0, 1, 1, w.err2, o.eps_mode, o.eps, o.l1,
-                              c_override, 1, s));
+                              c_override, 1, o.loss, s));
         HIP_TRY(utt_check(w.err2, w.u, n_utt, 0, o.check_every, o.stop_rule, o.tol, s));
         first = 0;
     }
@@ -173,7 +181,7 @@ int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_sol
         bool check = false;
         if (o.check_every > 0 && n >= o.check_every) { n = o.check_every; check = true; }
         HIP_TRY(fused_iterate(w.fl, w.fb, w.u, d.N, d.T_, n, first, check ? 1 : 0, w.err2, o.eps_mode,
-                              o.eps, o.l1, c_override, o.stop_rule == EVC_STOP_NONE ? 1 : 0, s));
+                              o.eps, o.l1, c_override, o.stop_rule == EVC_STOP_NONE ? 1 : 0, o.loss, s));
         first = 0;
         done += n;
         if (check)
@@ -238,6 +246,8 @@ int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int 
     HIP_TRY(copy2d<T>(A, lda, N, M, fm ? 0 : 1, w.At, d.Mk, d.Np, d.Mk, 0, s));
     HIP_TRY(copy2d<T>(A, lda, M, N, fm ? 1 : 0, w.Am, d.Np, d.Mj, d.Np, 0, s));
     HIP_TRY(copy2d<T>(X, ldx, T_, M, fm ? 0 : 1, w.Xt, d.Mk, d.Tp, d.Mk, 0, s));
+    const bool kl = (o.loss == EVC_LOSS_KL);
+    if (kl) HIP_TRY(kl_scale_dict<T>(w.At, d.Mk, M, d.Np, o.eps, w.Akl, s));
     if (o.init_mode == EVC_INIT_SKLEARN) HIP_TRY(utt_sklearn_h0<T>(w.Xt, d.Mk, M, N, w.u, n_utt, s));
     else if (o.init_mode == EVC_INIT_CONST) HIP_TRY(utt_const_h0(w.u, n_utt, o.init_value, s));
 
@@ -261,7 +271,7 @@ int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int 
     // ---- numerator (and Gram matrix) ----
     const bool gram = (algo == EVC_ALGO_GRAM || algo == EVC_ALGO_LITERAL);
     if (gram) HIP_TRY(gemm_nt<T>(w.At, d.Mk, w.At, d.Mk, w.G, d.Np, d.Np, d.Np, d.Mk, s));
-    HIP_TRY(gemm_nt<T>(w.Xt, d.Mk, w.At, d.Mk, w.Pt, d.Np, d.Tp, d.Np, d.Mk, s));
+    if (!kl) HIP_TRY(gemm_nt<T>(w.Xt, d.Mk, w.At, d.Mk, w.Pt, d.Np, d.Tp, d.Np, d.Mk, s));
 
     T* Hc = w.H0;       // current activations
     T* Hn = w.H1;       // ping-pong partner (GRAM only)
@@ -270,7 +280,8 @@ int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int 
     auto residual_check = [&](int c) -> int {
         if (!v_valid) HIP_TRY(gemm_nt<T>(Hc, d.Np, w.Am, d.Np, w.Vt, d.Mj, d.Tp, d.Mj, d.Np, s));
         v_valid = true;
-        HIP_TRY(frame_err2<T>(w.Xt, d.Mk, w.Vt, d.Mj, M, T_, w.err2, s));
+        if (kl) HIP_TRY(frame_err_kl<T>(w.Xt, d.Mk, w.Vt, d.Mj, M, T_, o.eps, w.err2, s));
+        else HIP_TRY(frame_err2<T>(w.Xt, d.Mk, w.Vt, d.Mj, M, T_, w.err2, s));
         HIP_TRY(utt_check(w.err2, w.u, n_utt, c, o.check_every, o.stop_rule, o.tol, s));
         return 0;
     };
@@ -282,7 +293,7 @@ int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int 
 
     MuEpilogue<T> ep;
     ep.P = w.Pt; ep.frame_utt = w.u.frame_utt; ep.active = w.u.active; ep.ldh = d.Np;
-    ep.N = N; ep.T_ = T_; ep.eps_mode = o.eps_mode; ep.eps = (T)o.eps; ep.l1 = (T)o.l1;
+    ep.N = N; ep.T_ = T_; ep.eps_mode = o.eps_mode; ep.eps = (T)o.eps; ep.l1 = (T)o.l1; ep.kl = kl ? 1 : 0;
 
     if (o.ev_loop_start) HIP_TRY(hipEventRecord((hipEvent_t)o.ev_loop_start, s));
     for (int it = 1; it <= o.iters; ++it) {
@@ -296,8 +307,13 @@ int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int 
             T* tmp = Hc; Hc = Hn; Hn = tmp;
         } else {
             if (!v_valid) HIP_TRY(gemm_nt<T>(Hc, d.Np, w.Am, d.Np, w.Vt, d.Mj, d.Tp, d.Mj, d.Np, s));
-            ep.Hin = Hc;                  // H' = mu(H, P, V At^T), V = H Am^T ; in place
-            HIP_TRY(gemm_nt_mu<T>(w.Vt, d.Mj, w.At, d.Mk, Hc, d.Tp, d.Np, d.Mk, ep, s));
+            ep.Hin = Hc;
+            if (kl) {                     // H' = H (.) (X (/) max(V, eps)) (A / colsum)   sklearn _nmf.py:556-606
+                HIP_TRY(kl_ratio<T>(w.Xt, d.Mk, w.Vt, d.Mj, M, d.Tp, o.eps, w.Rt, d.Mk, s));
+                HIP_TRY(gemm_nt_mu<T>(w.Rt, d.Mk, w.Akl, d.Mk, Hc, d.Tp, d.Np, d.Mk, ep, s));
+            } else {                      // H' = mu(H, P, V At^T), V = H Am^T ; in place
+                HIP_TRY(gemm_nt_mu<T>(w.Vt, d.Mj, w.At, d.Mk, Hc, d.Tp, d.Np, d.Mk, ep, s));
+            }
         }
         v_valid = false;
         if (o.check_every > 0 && it % o.check_every == 0) {
@@ -378,6 +394,11 @@ static int solve_checked(const void* A, int lda, const void* X, int ldx, void* H
     if (o.check_every < 0) return ST_BADARG;
     if (o.stop_rule != EVC_STOP_NONE && o.check_every == 0) return ST_BADARG;
     if (!(o.l1 >= 0.0)) return ST_BADARG;
+    if (o.loss != EVC_LOSS_FROBENIUS && o.loss != EVC_LOSS_KL) return ST_BADARG;
+    if (o.loss == EVC_LOSS_KL) {   // sklearn's KL update: its guards, no Gram shortcut, no (quirky) L1
+        if (o.eps_mode != EVC_EPS_ZERO_REPLACE || o.l1 != 0.0 || !(o.eps > 0.0)) return ST_UNSUPPORTED;
+        if (o.algo == EVC_ALGO_GRAM || o.algo == EVC_ALGO_LITERAL) return ST_UNSUPPORTED;
+    }
     if (y && y->Mb < 1) return ST_BADARG;
     if (T == 0) {
         if (n_iter_out) for (int i = 0; i < n_utt; ++i) n_iter_out[i] = 0;

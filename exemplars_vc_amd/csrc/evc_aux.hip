@@ -189,6 +189,80 @@ hipError_t frame_err2(const T* Xt, int ldx, const T* Vt, int ldv, int M, int T_,
     return hipGetLastError();
 }
 
+// ---- generalised Kullback-Leibler variant (sklearn _nmf.py:556-606, 136-160) ----
+// Akl[n][m] = At[n][m] / colsum_n, colsum_n == 0 -> eps (the constant denominator of the KL update,
+// folded into the dictionary once per call); one wavefront per exemplar
+template <typename T>
+__global__ __launch_bounds__(256) void k_kl_scale_dict(const T* __restrict__ At, int ld, int M, int rows,
+                                                       T eps, T* __restrict__ Akl) {
+    const long n = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= rows) return;
+    const int lane = threadIdx.x & 63;
+    double acc = 0.0;
+    for (int m = lane; m < M; m += 64) acc += (double)At[n * ld + m];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    T den = (T)acc;
+    den = (den == T(0)) ? eps : den;
+    for (int m = lane; m < ld; m += 64) Akl[n * ld + m] = (m < M) ? At[n * ld + m] / den : T(0);
+}
+template <typename T>
+hipError_t kl_scale_dict(const T* At, int ld, int M, int rows, double eps, T* Akl, hipStream_t s) {
+    hipLaunchKernelGGL((k_kl_scale_dict<T>), dim3((rows + 3) / 4), dim3(256), 0, s, At, ld, M, rows, (T)eps, Akl);
+    return hipGetLastError();
+}
+
+// R[t][m] = X[t][m] / max(V[t][m], eps)   (m < M, zero in the padding)
+template <typename T>
+__global__ __launch_bounds__(256) void k_kl_ratio(const T* __restrict__ Xt, int ldx, const T* __restrict__ Vt,
+                                                  int ldv, int M, long Tp, T eps, T* __restrict__ Rt, int ldr) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= Tp * ldr) return;
+    const long t = gid / ldr;
+    const int m = (int)(gid % ldr);
+    T r = T(0);
+    if (m < M) {
+        T v = Vt[t * ldv + m];
+        v = (v < eps) ? eps : v;
+        r = Xt[t * ldx + m] / v;
+    }
+    Rt[gid] = r;
+}
+template <typename T>
+hipError_t kl_ratio(const T* Xt, int ldx, const T* Vt, int ldv, int M, long Tp, double eps, T* Rt, int ldr,
+                    hipStream_t s) {
+    const long n = Tp * ldr;
+    hipLaunchKernelGGL((k_kl_ratio<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Xt, ldx, Vt, ldv, M,
+                       Tp, (T)eps, Rt, ldr);
+    return hipGetLastError();
+}
+
+// err2[t] = 2 * ( sum_{m: x > eps} (x log(x / max(v, eps)) - x) + sum_m v ): the per-frame share of
+// 2 KL(X || A H), so that sqrt(max(sum_t err2, 0)) is sklearn's _beta_divergence(beta=1, square_root=True)
+template <typename T>
+__global__ __launch_bounds__(256) void k_frame_err_kl(const T* __restrict__ Xt, int ldx, const T* __restrict__ Vt,
+                                                      int ldv, int M, int T_, double eps, double* __restrict__ err2) {
+    const long t = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T_) return;
+    const int lane = threadIdx.x & 63;
+    double acc = 0.0;
+    for (int m = lane; m < M; m += 64) {
+        const double x = (double)Xt[t * ldx + m], v = (double)Vt[t * ldv + m];
+        acc += v;
+        if (x > eps) acc += x * log(x / (v < eps ? eps : v)) - x;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if (lane == 0) err2[t] = 2.0 * acc;
+}
+template <typename T>
+hipError_t frame_err_kl(const T* Xt, int ldx, const T* Vt, int ldv, int M, int T_, double eps, double* err2,
+                        hipStream_t s) {
+    if (T_ <= 0) return hipSuccess;
+    hipLaunchKernelGGL((k_frame_err_kl<T>), dim3((T_ + 3) / 4), dim3(256), 0, s, Xt, ldx, Vt, ldv, M, T_, eps, err2);
+    return hipGetLastError();
+}
+
 // One block per utterance: err = sqrt(sum_t err2[t]); record it; apply the stopping rule.
 //   sklearn _nmf.py:871-884:  (previous_error - error) / error_at_init < tol  -> stop
 //   pymf base.py:189-206,266-270: for the third and later errors,
@@ -202,7 +276,7 @@ __global__ __launch_bounds__(256) void k_utt_check(const double* __restrict__ er
     const long t0 = u.offsets[id], t1 = u.offsets[id + 1];
     double acc = 0.0;
     for (long t = t0 + threadIdx.x; t < t1; t += 256) acc += err2[t];
-    const double err = sqrt(block_sum_256(acc, red));
+    const double err = sqrt(fmax(block_sum_256(acc, red), 0.0));   // (KL: rounding can leave a tiny negative sum)
     if (threadIdx.x != 0) return;
     u.trace[(long)id * u.n_slots + c] = err;
     if (c == 0) {
@@ -236,7 +310,10 @@ hipError_t utt_check(const double* err2, const UttState& u, int n_utt, int c, in
     template hipError_t copy2d<T>(const T*, long, int, int, int, T*, long, int, int, int, hipStream_t); \
     template hipError_t utt_sklearn_h0<T>(const T*, int, int, int, const UttState&, int, hipStream_t); \
     template hipError_t fill_h0<T>(T*, int, int, int, int, const UttState&, hipStream_t);           \
-    template hipError_t frame_err2<T>(const T*, int, const T*, int, int, int, double*, hipStream_t);
+    template hipError_t frame_err2<T>(const T*, int, const T*, int, int, int, double*, hipStream_t);        \
+    template hipError_t kl_scale_dict<T>(const T*, int, int, int, double, T*, hipStream_t);                \
+    template hipError_t kl_ratio<T>(const T*, int, const T*, int, int, long, double, T*, int, hipStream_t); \
+    template hipError_t frame_err_kl<T>(const T*, int, const T*, int, int, int, double, double*, hipStream_t);
 EVC_INST(double)
 EVC_INST(float)
 

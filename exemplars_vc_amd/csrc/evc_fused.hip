@@ -44,13 +44,13 @@ __global__ void k_pack_dict(const double* __restrict__ At, int ldA, int NT, int 
         const long j = (gid >> 7) / (msp / 2);
         const int i = l & 15;
         const long n = 16 * j + 4 * (i & 3) + (i >> 2);
-        A1p[gid] = s < msteps ? At[n * ldA + bin_of(s, l >> 4)] : 0.0;
+        if (A1p) A1p[gid] = s < msteps ? At[n * ldA + bin_of(s, l >> 4)] : 0.0;
     } else if (gid < n1 + n2) {
         const long g = gid - n1;
         const int e = g & 1, l = (g >> 1) & 63, r = 2 * (int)((g >> 7) & 1) + e, u = (g >> 8) % mtiles;
         const long j = (g >> 8) / mtiles;
         const long n = 16 * j + 4 * (l >> 4) + r;
-        A2p[g] = At[n * ldA + 16 * u + (l & 15)];
+        if (A2p) A2p[g] = At[n * ldA + 16 * u + (l & 15)];
     }
 }
 
@@ -161,6 +161,8 @@ __global__ __launch_bounds__(NW * 64) void k_fused_mu(FusedArgs a) {
     double* red = lds;                           // [NW][E]   partial V' of every wavefront
     double* vL = lds + NW * E;                   // [C][MT*4][64]  V, B-operand order
     double* xL = vL + E;                         // [C][MT*4][64]  X, B-operand order
+    double* rL = xL + E;                         // [C][MT*4][64]  X / max(V, eps) (KL numerator operand)
+    const bool kl = a.loss == EVC_LOSS_KL;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: scalar loop and addresses
     const int q = lane >> 4;
@@ -191,8 +193,11 @@ __global__ __launch_bounds__(NW * 64) void k_fused_mu(FusedArgs a) {
     for (int e = tid; e < E; e += NW * 64) {
         const int c = e / (MT * 256), s = (e >> 6) % (MT * 4), l = e & 63;
         const bool in = (tt0 + c < a.TT) && s < MSTEPS;
-        xL[e] = in ? a.Xp[((tt0 + c) * MSTEPS + s) * 64 + l] : 0.0;
-        vL[e] = (in && !a.first) ? a.Vp[((tt0 + c) * 8 + s) * 64 + l] : 0.0;
+        const double x = in ? a.Xp[((tt0 + c) * MSTEPS + s) * 64 + l] : 0.0;
+        const double v = (in && !a.first) ? a.Vp[((tt0 + c) * 8 + s) * 64 + l] : 0.0;
+        xL[e] = x;
+        vL[e] = v;
+        rL[e] = x / (v < a.eps ? a.eps : v);
     }
     __syncthreads();
 
@@ -237,6 +242,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused_mu(FusedArgs a) {
 #pragma unroll
             for (int ww = 0; ww < NW; ++ww) acc += red[ww * E + e];
             vL[e] = acc;
+            if (kl) rL[e] = xL[e] / (acc < a.eps ? a.eps : acc);     // sklearn _nmf.py:572-576
         }
         __syncthreads();
     };
@@ -270,9 +276,10 @@ __global__ __launch_bounds__(NW * 64) void k_fused_mu(FusedArgs a) {
     const bool masked = !__syncthreads_and(all_live) || (a.N & 15) != 0;
     const double eps = a.eps;
 
-    auto sweep = [&](auto mul_first_tag, auto masked_tag) {
+    auto sweep = [&](auto mul_first_tag, auto masked_tag, auto kl_tag) {
         constexpr bool MUL_FIRST = decltype(mul_first_tag)::value;
         constexpr bool MASKED = decltype(masked_tag)::value;
+        constexpr bool KL = decltype(kl_tag)::value;
         const int mode = a.eps_mode;
         // l1 (sklearn _nmf.py:615-617) and pymf's +eps (nmf.py:68) ride in the accumulator's start value
         const double d0 = a.l1 + (mode == EVC_EPS_ADD ? a.eps : 0.0);
@@ -291,21 +298,31 @@ __global__ __launch_bounds__(NW * 64) void k_fused_mu(FusedArgs a) {
                 for (int c = 0; c < C; ++c) {
                     if (MASKED && tt0 + c >= a.TT) continue;     // uniform
                     f64x4 d = dinit, p = {0, 0, 0, 0};
+                    if (KL) {      // p <- (A_j / colsum)^T (X / max(V, eps)): the complete KL factor
 #pragma unroll
-                    for (int s = 0; s < MSTEPS; ++s) {
-                        d = Mma<double>::mma(R.a1[s], vL[(c * MT * 4 + s) * 64 + lane], d);
-                        p = Mma<double>::mma(R.a1[s], xL[(c * MT * 4 + s) * 64 + lane], p);
+                        for (int s = 0; s < MSTEPS; ++s)
+                            p = Mma<double>::mma(R.a1[s], rL[(c * MT * 4 + s) * 64 + lane], p);
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < MSTEPS; ++s) {
+                            d = Mma<double>::mma(R.a1[s], vL[(c * MT * 4 + s) * 64 + lane], d);
+                            p = Mma<double>::mma(R.a1[s], xL[(c * MT * 4 + s) * 64 + lane], p);
+                        }
                     }
                     double h[4] = {R.h01[c][0], R.h01[c][1], R.h23[c][0], R.h23[c][1]};
                     if (MASKED) {
                         double hn[4] = {h[0], h[1], h[2], h[3]};
-                        mu_tile<MUL_FIRST>(hn, p, d, mode, eps, lo);
+                        if (KL) { for (int r = 0; r < 4; ++r) hn[r] *= p[r]; }
+                        else mu_tile<MUL_FIRST>(hn, p, d, mode, eps, lo);
                         const int n0 = 16 * j + 4 * q;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const double v = (n0 + r < a.N) ? hn[r] : 0.0;   // exemplar padding stays 0
                             h[r] = live[c] ? v : h[r];                      // stopped utterances are frozen
                         }
+                    } else if (KL) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) h[r] *= p[r];
                     } else {
                         mu_tile<MUL_FIRST>(h, p, d, mode, eps, lo);
                     }
@@ -322,12 +339,15 @@ __global__ __launch_bounds__(NW * 64) void k_fused_mu(FusedArgs a) {
         }
     };
     const bool mul_first = a.eps_mode == EVC_EPS_ADD || a.eps_mode == EVC_EPS_NONE;
-    if (mul_first) {
-        if (masked) sweep(std::true_type{}, std::true_type{});
-        else sweep(std::true_type{}, std::false_type{});
+    if (kl) {
+        if (masked) sweep(std::false_type{}, std::true_type{}, std::true_type{});
+        else sweep(std::false_type{}, std::false_type{}, std::true_type{});
+    } else if (mul_first) {
+        if (masked) sweep(std::true_type{}, std::true_type{}, std::false_type{});
+        else sweep(std::true_type{}, std::false_type{}, std::false_type{});
     } else {
-        if (masked) sweep(std::false_type{}, std::true_type{});
-        else sweep(std::false_type{}, std::false_type{});
+        if (masked) sweep(std::false_type{}, std::true_type{}, std::false_type{});
+        else sweep(std::false_type{}, std::false_type{}, std::false_type{});
     }
 
     // carry V to the next launch; per-frame squared residual of the final activations
@@ -340,8 +360,8 @@ __global__ __launch_bounds__(NW * 64) void k_fused_mu(FusedArgs a) {
         double e = 0.0;
 #pragma unroll
         for (int s = 0; s < MSTEPS; ++s) {
-            const double df = xL[(c * MT * 4 + s) * 64 + lane] - vL[(c * MT * 4 + s) * 64 + lane];
-            e += df * df;
+            const double x = xL[(c * MT * 4 + s) * 64 + lane], v = vL[(c * MT * 4 + s) * 64 + lane];
+            e += kl ? kl_terms(x, v, a.eps) : (x - v) * (x - v);
         }
         e += __shfl_xor(e, 16, 64);      // the 4 lane groups hold one frame's bins
         e += __shfl_xor(e, 32, 64);
@@ -414,7 +434,7 @@ template <int MSTEPS, int C>
 static hipError_t launch_fused(const FusedArgs& a, hipStream_t s) {
     constexpr int MT = MSTEPS > 4 ? 2 : 1;
     constexpr int E = C * MT * 4 * 64;
-    const size_t lds = (size_t)(NW + 2) * E * sizeof(double);
+    const size_t lds = (size_t)(NW + 3) * E * sizeof(double);
     const unsigned grid = (unsigned)((a.TT + C - 1) / C);
     if (lds > 48 * 1024) {   // per-launch, so that no mutable global state is kept
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_mu<MSTEPS, C>),
@@ -456,12 +476,13 @@ static hipError_t launch_general(const FusedLayout& f, const FusedArgs& a, int c
 // all_live_known: no stopping rule is in force, so every utterance is active for the whole call.
 hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttState& u, int N, int T_,
                          int iters, int first, int write_err, double* err2, int eps_mode, double eps,
-                         double l1, int c_req, int all_live_known, hipStream_t s) {
+                         double l1, int c_req, int all_live_known, int loss, hipStream_t s) {
     FusedArgs a;
     a.A1p = b.A1p; a.A2p = b.A2p; a.Xp = b.Xp; a.Hp = reinterpret_cast<f64x2*>(b.Hp); a.Vp = b.Vp;
     a.err2 = err2; a.frame_utt = u.frame_utt; a.active = u.active;
     a.NT = f.NT; a.TT = f.TT; a.N = N; a.T_ = T_;
     a.iters = iters; a.first = first; a.write_err = write_err; a.skip_all_live = 0; a.force_live = 0;
+    a.loss = loss;
     a.eps_mode = eps_mode; a.eps = eps; a.l1 = l1;
     const bool resident = c_req == 0 && fused_res_supported(N, eps_mode);
     if (!resident) return launch_general(f, a, c_req, s);
@@ -490,7 +511,7 @@ hipError_t fused_synthesize(const FusedLayout& fB, const double* B2p, const doub
     a.Hp = reinterpret_cast<f64x2*>(const_cast<double*>(Hp)); a.Vp = Yp;
     a.err2 = nullptr; a.frame_utt = u.frame_utt; a.active = u.active;
     a.NT = fB.NT; a.TT = fB.TT; a.N = N; a.T_ = T_;
-    a.iters = 0; a.first = 1; a.write_err = 0; a.skip_all_live = 0; a.force_live = 1;
+    a.iters = 0; a.first = 1; a.write_err = 0; a.skip_all_live = 0; a.force_live = 1; a.loss = EVC_LOSS_FROBENIUS;
     a.eps_mode = EVC_EPS_ADD; a.eps = 0; a.l1 = 0;
     hipError_t e = dispatch_msteps<1>(fB.msteps, a, s);
     if (e != hipSuccess) return e;

@@ -41,6 +41,7 @@ struct FusedArgs {
     int write_err;
     int skip_all_live;       // 1: workgroups whose frames are all live were done by k_fused_res
     int force_live;          // 1: ignore the utterances' active flags (synthesis pre-pass)
+    int loss;                // EVC_LOSS_*; for KL A1p holds the dictionary pre-divided by its column sums
     int eps_mode;
     double eps, l1;
 };
@@ -105,6 +106,14 @@ __device__ __forceinline__ void mu_tile(double (&h)[4], const f64x4& p, const f6
 }
 
 hipError_t fused_res_launch(int msteps, const FusedArgs& a, hipStream_t s);
+
+// per-frame share of 2 KL(X || A H) from the B-operand images of X and V held by one lane
+// (sklearn _nmf.py:136-160: log term only where x > eps, V floored at eps there, plus sum(V))
+__device__ __forceinline__ double kl_terms(double x, double v, double eps) {
+    double e = v;
+    if (x > eps) e += x * log(x / (v < eps ? eps : v)) - x;
+    return 2.0 * e;
+}
 bool fused_res_supported(int N, int eps_mode);
 
 }  // namespace evc

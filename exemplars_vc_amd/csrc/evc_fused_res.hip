@@ -35,7 +35,9 @@ namespace evc {
 
 constexpr int RNW = 8;    // wavefronts per workgroup
 
-template <int MSTEPS, int RES, int PL>
+// KL: the generalised Kullback-Leibler update (A1p holds the dictionary divided by its column sums; the
+// per-unit work is one MFMA chain (A_j/colsum)^T (X / max(V, eps)) and a multiply, no division).
+template <int MSTEPS, int RES, int PL, bool KL>
 __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
     constexpr int MT = MSTEPS > 4 ? 2 : 1;
     constexpr int E = MT * 4 * 64;               // doubles in one V (accumulator order)
@@ -43,9 +45,10 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
     double* red = lds;                           // [RNW][E]  partial V' of every wavefront
     double* vL = lds + RNW * E;                  // [MT*4][64]  V, B-operand order
     double* xL = vL + E;                         // [MT*4][64]  X, B-operand order
+    double* rL = xL + E;                         // [MT*4][64]  X / max(V, eps): KL numerator operand
     // numerator tiles P = A_j^T X of the first PL tiles of every wavefront: computed in the first sweep
     // of a launch, read back afterwards (7 fewer MFMAs per unit; LDS would otherwise sit idle)
-    f64x2* pL = reinterpret_cast<f64x2*>(xL + E) + (size_t)(threadIdx.x >> 6) * (PL * 128);   // [PL][2][64] per wavefront
+    f64x2* pL = reinterpret_cast<f64x2*>(rL + E) + (size_t)(threadIdx.x >> 6) * (PL * 128);   // [PL][2][64] per wavefront
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long tt = blockIdx.x;
@@ -66,8 +69,11 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
     for (int e = tid; e < E; e += RNW * 64) {
         const int s = e >> 6, l = e & 63;
         const bool in = s < MSTEPS;
-        xL[e] = in ? a.Xp[(tt * MSTEPS + s) * 64 + l] : 0.0;
-        vL[e] = in ? a.Vp[(tt * 8 + s) * 64 + l] : 0.0;
+        const double x = in ? a.Xp[(tt * MSTEPS + s) * 64 + l] : 0.0;
+        const double v = in ? a.Vp[(tt * 8 + s) * 64 + l] : 0.0;
+        xL[e] = x;
+        vL[e] = v;
+        rL[e] = x / (v < a.eps ? a.eps : v);
     }
     __syncthreads();
 
@@ -140,7 +146,10 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
     int it = 0;
     // D (and P, unless tile k's numerator is cached in LDS: k < PL and not the first sweep)
     auto dp = [&](const double (&a1)[MSTEPS], f64x4& d, f64x4& p, int k) {
-        if (k < PL && it > 0) {
+        if (KL) {
+#pragma unroll
+            for (int s = 0; s < MSTEPS; ++s) p = Mma<double>::mma(a1[s], rL[s * 64 + lane], p);
+        } else if (k < PL && it > 0) {
 #pragma unroll
             for (int s = 0; s < MSTEPS; ++s) d = Mma<double>::mma(a1[s], vL[s * 64 + lane], d);
             const f64x2 p01 = pL[(k * 2) * 64 + lane], p23 = pL[(k * 2 + 1) * 64 + lane];
@@ -165,7 +174,8 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
         dp(a1, d, p, k);
         if (more) load_a1(a1, k + 1);            // operand registers are free once the MFMAs issued
         __builtin_amdgcn_sched_barrier(0);
-        mu_tile<false>(h, p, d, mode, eps, lo);
+        if (KL) { for (int r = 0; r < 4; ++r) h[r] *= p[r]; }
+        else mu_tile<false>(h, p, d, mode, eps, lo);
     };
 
     double hres[RES][4];
@@ -199,7 +209,8 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
                 dp(a1, d, p, 2 * k2 + 1);
                 if (more) load_a1(a1, 2 * k2 + 2);
                 __builtin_amdgcn_sched_barrier(0);
-                mu_tile<false>(hs[k2 & 1], p, d, mode, eps, lo);
+                if (KL) { for (int r = 0; r < 4; ++r) hs[k2 & 1][r] *= p[r]; }
+                else mu_tile<false>(hs[k2 & 1], p, d, mode, eps, lo);
             }
             // the next streamed tile's load goes out here, two units ahead of its use (after the update:
             // registers with a load in flight must not cross the update's rare-path merge)
@@ -230,6 +241,7 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
 #pragma unroll
             for (int ww = 0; ww < RNW; ++ww) acc += red[ww * E + e];
             vL[e] = acc;
+            if (KL) rL[e] = xL[e] / (acc < a.eps ? a.eps : acc);     // sklearn _nmf.py:572-576
         }
         __syncthreads();
     }
@@ -246,8 +258,8 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
         double e = 0.0;
 #pragma unroll
         for (int s = 0; s < MSTEPS; ++s) {
-            const double df = xL[s * 64 + lane] - vL[s * 64 + lane];
-            e += df * df;
+            const double x = xL[s * 64 + lane], v = vL[s * 64 + lane];
+            e += KL ? kl_terms(x, v, a.eps) : (x - v) * (x - v);
         }
         e += __shfl_xor(e, 16, 64);      // the 4 lane groups hold one frame's bins
         e += __shfl_xor(e, 32, 64);
@@ -256,28 +268,33 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
     }
 }
 
-template <int MSTEPS, int RES>
+template <int MSTEPS, int RES, bool KL>
 static hipError_t launch_res(const FusedArgs& a, hipStream_t s) {
     constexpr int MT = MSTEPS > 4 ? 2 : 1;
     constexpr int E = MT * 4 * 64;
-    constexpr int PL = EVC_RES_PL;
-    const size_t lds = (size_t)(RNW + 2) * E * sizeof(double) + (size_t)RNW * PL * 256 * sizeof(double);
+    constexpr int PL = KL ? 0 : EVC_RES_PL;
+    const size_t lds = (size_t)(RNW + 3) * E * sizeof(double) + (size_t)RNW * PL * 256 * sizeof(double);
     if (lds > 64 * 1024) {   // per launch: no mutable global state is kept
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_res<MSTEPS, RES, PL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_res<MSTEPS, RES, PL, KL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_fused_res<MSTEPS, RES, PL>), dim3((unsigned)a.TT), dim3(RNW * 64), lds, s, a);
+    hipLaunchKernelGGL((k_fused_res<MSTEPS, RES, PL, KL>), dim3((unsigned)a.TT), dim3(RNW * 64), lds, s, a);
     return hipGetLastError();
 }
 
-template <int MSTEPS>
+template <int MSTEPS, bool KL>
 static hipError_t pick_res(const FusedArgs& a, hipStream_t s) {
     const int KT = a.NT / RNW;
-    if (KT >= 2 * EVC_RES_MAX) return launch_res<MSTEPS, EVC_RES_MAX>(a, s);
-    if (KT >= 16) return launch_res<MSTEPS, 8>(a, s);
-    if (KT >= 8) return launch_res<MSTEPS, 4>(a, s);
+    if (KT >= 2 * EVC_RES_MAX) return launch_res<MSTEPS, EVC_RES_MAX, KL>(a, s);
+    if (KT >= 16) return launch_res<MSTEPS, 8, KL>(a, s);
+    if (KT >= 8) return launch_res<MSTEPS, 4, KL>(a, s);
     return hipErrorInvalidValue;
+}
+
+template <int MSTEPS>
+static hipError_t pick_loss(const FusedArgs& a, hipStream_t s) {
+    return a.loss == EVC_LOSS_KL ? pick_res<MSTEPS, true>(a, s) : pick_res<MSTEPS, false>(a, s);
 }
 
 bool fused_res_supported(int N, int eps_mode) {
@@ -286,14 +303,14 @@ bool fused_res_supported(int N, int eps_mode) {
 
 hipError_t fused_res_launch(int msteps, const FusedArgs& a, hipStream_t s) {
     switch (msteps) {
-        case 1: return pick_res<1>(a, s);
-        case 2: return pick_res<2>(a, s);
-        case 3: return pick_res<3>(a, s);
-        case 4: return pick_res<4>(a, s);
-        case 5: return pick_res<5>(a, s);
-        case 6: return pick_res<6>(a, s);
-        case 7: return pick_res<7>(a, s);
-        case 8: return pick_res<8>(a, s);
+        case 1: return pick_loss<1>(a, s);
+        case 2: return pick_loss<2>(a, s);
+        case 3: return pick_loss<3>(a, s);
+        case 4: return pick_loss<4>(a, s);
+        case 5: return pick_loss<5>(a, s);
+        case 6: return pick_loss<6>(a, s);
+        case 7: return pick_loss<7>(a, s);
+        case 8: return pick_loss<8>(a, s);
         default: return hipErrorInvalidValue;
     }
 }

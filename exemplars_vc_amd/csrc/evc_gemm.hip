@@ -129,8 +129,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_gemm_nt(
                     const T h = ep.Hin[row * ep.ldh + col];
                     T out = h;
                     if (live) {
-                        const T p = ep.P[row * ep.ldh + col];
-                        out = mu_update<T>(h, p, acc[mi][ni][r], ep.eps_mode, ep.eps, ep.l1);
+                        if (ep.kl) {
+                            out = h * acc[mi][ni][r];
+                        } else {
+                            const T p = ep.P[row * ep.ldh + col];
+                            out = mu_update<T>(h, p, acc[mi][ni][r], ep.eps_mode, ep.eps, ep.l1);
+                        }
                         if (col >= ep.N) out = T(0);   // keep the zero padding exact (0/0 modes)
                     }
                     C[row * ldc + col] = out;

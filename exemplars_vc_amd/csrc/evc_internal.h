@@ -75,6 +75,7 @@ template <typename T> struct MuEpilogue {
     int N, T_;           // true (unpadded) sizes
     int eps_mode;
     T eps, l1;
+    int kl;              // 1: Hout = Hin * acc (the KL numerator over a pre-scaled dictionary); P unused
 };
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -112,6 +113,15 @@ hipError_t fill_h0(T* Ht, int ldh, int Tp, int N, int T_, const UttState& u, hip
 template <typename T>
 hipError_t frame_err2(const T* Xt, int ldx, const T* Vt, int ldv, int M, int T_, double* err2,
                       hipStream_t s);
+// generalised KL variant: dictionary scaled by 1/colsum, ratio X / max(V, eps), per-frame 2*KL
+template <typename T>
+hipError_t kl_scale_dict(const T* At, int ld, int M, int rows, double eps, T* Akl, hipStream_t s);
+template <typename T>
+hipError_t kl_ratio(const T* Xt, int ldx, const T* Vt, int ldv, int M, long Tp, double eps, T* Rt, int ldr,
+                    hipStream_t s);
+template <typename T>
+hipError_t frame_err_kl(const T* Xt, int ldx, const T* Vt, int ldv, int M, int T_, double eps, double* err2,
+                        hipStream_t s);
 // evaluate the stopping rule after check number `c` (c == 0: error at init)
 hipError_t utt_check(const double* err2, const UttState& u, int n_utt, int c, int check_every,
                      int stop_rule, double tol, hipStream_t s);
@@ -131,6 +141,7 @@ struct FusedBuffers {
 bool fused_supported(int M, int N, int T_, int dtype);
 FusedLayout fused_layout(int M, int N, int T_);
 // At[n][m] / Xt[t][m]: the zero-padded frames-as-rows workspace arrays
+// (either destination may be NULL: only the other fragment order is written)
 hipError_t fused_pack_dict(const FusedLayout& f, double* A1p, double* A2p, const double* At, int ldA,
                            hipStream_t s);
 hipError_t fused_pack_frames(const FusedLayout& f, double* Xp, const double* Xt, int ldx, hipStream_t s);
@@ -148,6 +159,6 @@ hipError_t fused_synthesize(const FusedLayout& fB, const double* B2p, const doub
 // Vp from the previous launch); write_err: per-frame squared residuals of the final H -> err2.
 hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttState& u, int N, int T_,
                          int iters, int first, int write_err, double* err2, int eps_mode, double eps,
-                         double l1, int c_req, int all_live_known, hipStream_t s);
+                         double l1, int c_req, int all_live_known, int loss, hipStream_t s);
 
 }  // namespace evc

@@ -26,6 +26,7 @@ _ALGOS = {"gram": _lib.ALGO_GRAM, "factored": _lib.ALGO_FACTORED, "literal": _li
 _INITS = {"given": _lib.INIT_GIVEN, "sklearn": _lib.INIT_SKLEARN, "const": _lib.INIT_CONST}
 _STOPS = {"none": _lib.STOP_NONE, "sklearn": _lib.STOP_SKLEARN, "pymf": _lib.STOP_PYMF}
 _LAYOUTS = {"frame_major": _lib.FRAME_MAJOR, "bin_major": _lib.BIN_MAJOR}
+_LOSSES = {"frobenius": _lib.LOSS_FROBENIUS, "kullback-leibler": _lib.LOSS_KL, "kl": _lib.LOSS_KL}
 
 _workspaces = {}
 
@@ -131,7 +132,7 @@ def _solve(A, X, H0, B, *, layout="bin_major", iters=100, eps_mode="add", eps=No
            l1=0.0, algo="auto", init=None, init_value=0.0, check_every=0,
            stop_rule="none", tol=0.0, utt_offsets: Optional[Sequence[int]] = None,
            dtype=None, device=None, info=False, out=None, loop_events=None,
-           fused=True, fused_c=0, want_h=True, out_y=None):
+           fused=True, fused_c=0, want_h=True, out_y=None, loss="frobenius"):
     torch = _torch()
     device = require_device(device)
     L = _lib.lib()
@@ -194,6 +195,7 @@ def _solve(A, X, H0, B, *, layout="bin_major", iters=100, eps_mode="add", eps=No
     opts.check_every, opts.stop_rule = int(check_every), _STOPS[stop_rule]
     opts.eps = _EPS_DEFAULT[eps_mode] if eps is None else float(eps)
     opts.l1, opts.tol, opts.init_value = float(l1), float(tol), float(init_value)
+    opts.loss = _LOSSES[loss]
     # testing knobs: bit 0 disables the fused persistent kernels; bits 8..15 = 1 or 2 force the
     # general streamed kernel with that many frame tiles per workgroup (0 = automatic)
     opts.reserved = (0 if fused else 1) | ((int(fused_c) & 0xff) << 8)

@@ -79,6 +79,14 @@ enum { EVC_INIT_GIVEN = 0, EVC_INIT_SKLEARN = 1, EVC_INIT_CONST = 2 };
  *            (pymf/base.py:189-206,266-270)                                               */
 enum { EVC_STOP_NONE = 0, EVC_STOP_SKLEARN = 1, EVC_STOP_PYMF = 2 };
 
+/* divergence minimised by the multiplicative update
+ *   FROBENIUS  H <- H (.) A^T X (/) (A^T A H)                       (what the scripts force, :210)
+ *   KL         H <- H (.) A^T (X (/) max(A H, eps)) (/) colsum(A)   generalised Kullback-Leibler: the
+ *              default of _factorize's signature (04_align_n_nmf.py:194), sklearn _nmf.py:556-606;
+ *              requires EVC_EPS_ZERO_REPLACE (sklearn's guards) and l1 == 0; the residual reported
+ *              to the stopping rule is sqrt(2 KL(X || A H)) (_nmf.py:136-160)                      */
+enum { EVC_LOSS_FROBENIUS = 0, EVC_LOSS_KL = 1 };
+
 typedef struct evc_solve_opts {
     int struct_bytes;  /* sizeof(evc_solve_opts), for forward compatibility */
     int dtype;         /* EVC_F64 | EVC_F32 */
@@ -89,7 +97,9 @@ typedef struct evc_solve_opts {
     int init_mode;     /* EVC_INIT_* */
     int check_every;   /* 0: never evaluate the residual; k>0: every k iterations */
     int stop_rule;     /* EVC_STOP_* */
-    int reserved;
+    int reserved;      /* 0 (testing knobs) */
+    int loss;          /* EVC_LOSS_* */
+    int reserved2;     /* 0 */
     double eps;        /* guard value for eps_mode */
     double l1;         /* added to the denominator (sklearn l1_reg_W = M*alpha_W*l1_ratio) */
     double tol;        /* threshold of stop_rule */

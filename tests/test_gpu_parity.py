@@ -81,6 +81,49 @@ def test_factorize_surface(path):
     assert_close64(convert(H, g["B_rows"]), g["Y_rows"], "Y")
 
 
+# ----------------------------------------------------------------------------------------
+# the KL loss of `_factorize`'s signature (sklearn beta_loss='kullback-leibler')
+# ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("path", golden_files("sklearnkl_"), ids=os.path.basename)
+@pytest.mark.parametrize("algo", ["factored", "factored_generic", "fused_c1", "fused_c2"])
+def test_sklearn_kl_golden(path, algo):
+    import exemplars_vc_amd as evc
+    g = load_golden(path)
+    tol, max_iter = float(g["tol"]), int(g["max_iter"])
+    act, info = evc.solve_activations(
+        g["W_rows"], g["X_rows"], layout="frame_major", iters=max_iter, eps_mode="zero_replace",
+        init="sklearn", check_every=10 if tol > 0 else 0, stop_rule="sklearn" if tol > 0 else "none",
+        tol=tol, info=True, loss="kullback-leibler", **variant_kw(algo))
+    assert int(info["n_iter"][0]) == int(g["n_iter"]), (info["n_iter"], g["n_iter"])
+    assert_close64(act.T, g["H"], f"KL H {os.path.basename(path)} {algo}")
+
+
+@pytest.mark.parametrize("N", [1024, 4096])
+def test_kl_on_the_register_resident_kernel(N):
+    import exemplars_vc_amd as evc
+    from exemplars_vc_amd.compat.factorize import _factorize
+    o = oracle()
+    p = o.synth_problem(25, N, 45, seed=N + 7)
+    X = np.ascontiguousarray(p["X"].T)
+    X[7] = 0.0
+    W = np.ascontiguousarray(p["A"].T)
+    want, n, _ = o.sklearn_mu_fixed_dictionary_kl(X, W, 40, 0.0)
+    got = evc.solve_activations(W, X, layout="frame_major", iters=40, eps_mode="zero_replace", init="sklearn",
+                                loss="kl")
+    assert_close64(got, want, "KL resident")
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        H = _factorize(X, W, beta_loss="kullback-leibler", tol=1e-3, honor_beta_loss=True)
+    want, n, _ = o.sklearn_mu_fixed_dictionary_kl(X, W, 150, 1e-3)
+    assert_close64(H, want.T, "KL _factorize")
+    # unsupported combinations are refused, not silently changed
+    with pytest.raises(Exception, match="unsupported"):
+        evc.solve_activations(W, X, layout="frame_major", iters=2, eps_mode="add", loss="kl")
+    with pytest.raises(Exception, match="unsupported"):
+        evc.solve_activations(W, X, layout="frame_major", iters=2, eps_mode="zero_replace", loss="kl", algo="gram")
+
+
 def test_factorize_batched_utterances_match_single_calls():
     """Per-utterance semantics (own init value, own stop iteration) inside one batch."""
     from exemplars_vc_amd.compat.factorize import factorize_utterances

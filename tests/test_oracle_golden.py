@@ -24,6 +24,15 @@ def test_sklearn_restatement_is_bit_exact(path):
     assert np.array_equal(o.s4_convert(act.T, g["B_rows"]), g["Y_rows"])
 
 
+@pytest.mark.parametrize("path", golden_files("sklearnkl_"), ids=os.path.basename)
+def test_sklearn_kl_restatement_is_bit_exact(path):
+    """the Kullback-Leibler default of `_factorize`'s signature, through scikit-learn."""
+    g = load_golden(path)
+    act, n_iter, _ = o.sklearn_mu_fixed_dictionary_kl(g["X_rows"], g["W_rows"], int(g["max_iter"]), float(g["tol"]))
+    assert n_iter == int(g["n_iter"])
+    assert np.array_equal(act.T, g["H"])
+
+
 def test_s1_factorize_matches_live_call_defaults():
     g = load_golden([p for p in golden_files("sklearn_") if p.endswith("m201_n128_t40_tol.npz")][0])
     H = o.s1_factorize(g["X_rows"], g["W_rows"], beta_loss="kullback-leibler", tol=1e-4)

@@ -51,19 +51,19 @@ def synth(M, N, T, seed, active=8, Mb=None):
     return A, B, X
 
 
-def run_sklearn(X_rows, W_rows, tol, max_iter=150, alpha_W=0.0, l1_ratio=0.0):
+def run_sklearn(X_rows, W_rows, tol, max_iter=150, alpha_W=0.0, l1_ratio=0.0, beta_loss="frobenius"):
     from sklearn.decomposition import non_negative_factorization
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         _W, _H, n_iter = non_negative_factorization(
             X=X_rows, H=W_rows, init="custom", update_H=False, n_components=W_rows.shape[0],
-            beta_loss="frobenius", solver="mu", tol=tol, max_iter=max_iter, verbose=0,
+            beta_loss=beta_loss, solver="mu", tol=tol, max_iter=max_iter, verbose=0,
             alpha_W=alpha_W, l1_ratio=l1_ratio)
     return _W, n_iter
 
 
 def sklearn_case(name, M, N, T, seed, tol, max_iter=150, alpha_W=0.0, l1_ratio=0.0,
-                 zero_cols=0, A=None, B=None, X=None):
+                 zero_cols=0, A=None, B=None, X=None, beta_loss="frobenius"):
     if A is None:
         A, B, X = synth(M, N, T, seed)
     if zero_cols:
@@ -74,12 +74,12 @@ def sklearn_case(name, M, N, T, seed, tol, max_iter=150, alpha_W=0.0, l1_ratio=0
     X_rows = np.ascontiguousarray(X.T)      # T x M  (script orientation)
     W_rows = np.ascontiguousarray(A.T)      # N x M
     B_rows = np.ascontiguousarray(B.T)      # N x Mb
-    act, n_iter = run_sklearn(X_rows, W_rows, tol, max_iter, alpha_W, l1_ratio)
+    act, n_iter = run_sklearn(X_rows, W_rows, tol, max_iter, alpha_W, l1_ratio, beta_loss)
     H = act.T                               # what _factorize returns (N x T)
     Y_rows = np.matmul(H.T, B_rows)         # convert(): T x Mb
     np.savez_compressed(
         os.path.join(OUT, name + ".npz"),
-        surface="sklearn", X_rows=X_rows, W_rows=W_rows, B_rows=B_rows, H=np.ascontiguousarray(H),
+        surface="sklearn", beta_loss=beta_loss, X_rows=X_rows, W_rows=W_rows, B_rows=B_rows, H=np.ascontiguousarray(H),
         Y_rows=Y_rows, n_iter=n_iter, tol=tol, max_iter=max_iter,
         l1_reg=X_rows.shape[1] * alpha_W * l1_ratio, alpha_W=alpha_W, l1_ratio=l1_ratio)
     print(f"{name}: T={X_rows.shape[0]} M={X_rows.shape[1]} N={W_rows.shape[0]} n_iter={n_iter}")
@@ -175,6 +175,12 @@ def main():
     sklearn_case("sklearn_l1_m25_n256_t64_k100", 25, 256, 64, 106, tol=0.0, max_iter=100,
                  alpha_W=0.01, l1_ratio=1.0)
     audio_case()
+    # the KL default of _factorize's signature (overridden by the script at :210)
+    kl = "kullback-leibler"
+    sklearn_case("sklearnkl_m25_n64_t32_k50", 25, 64, 32, 301, tol=0.0, max_iter=50, beta_loss=kl)
+    sklearn_case("sklearnkl_m201_n128_t40_tol", 201, 128, 40, 302, tol=1e-4, beta_loss=kl)
+    sklearn_case("sklearnkl_m25_n64_t50_tol2e-2", 25, 64, 50, 303, tol=2e-2, beta_loss=kl)
+    sklearn_case("sklearnkl_zero_frames", 25, 64, 24, 304, tol=0.0, max_iter=30, zero_cols=3, beta_loss=kl)
     # G3/G4: pymf
     try:
         NMF = import_pymf()
