@@ -3,5 +3,6 @@
   factorize  - `_factorize` / `convert` of 04_align_n_nmf.py (the scikit-learn based live path)
   pymf       - `pymf.nmf.NMF(data, num_bases).factorize(compute_w=False)`
   nmf_tool   - `nmf_tool.nmf.NMF(...).fit_transform(X, r, initW=True, givenW=A)`
+  griffin_lim - `zz_audio_utilities.reconstruct_signal_griffin_lim` (the STFT back end)
 """
-from . import factorize, nmf_tool, pymf  # noqa: F401
+from . import factorize, griffin_lim, nmf_tool, pymf  # noqa: F401

@@ -497,4 +497,19 @@ int evc_residual(const void* A, int lda, const void* X, int ldx, const void* H, 
     return ST_OK;
 }
 
+size_t evc_griffin_lim_workspace_bytes(int T, int fft_size, int hop, int iters) {
+    if (T < 1 || fft_size < 2 || (fft_size & 1) || hop < 1 || iters < 0) return 0;
+    return gl_workspace_bytes(T, fft_size, hop, iters);
+}
+
+int evc_griffin_lim(const void* mag, int ldm, int T, int fft_size, int hop, int iters, void* x,
+                    void* workspace, size_t workspace_bytes, double* rmse_out, evc_stream_t stream) {
+    if (T < 0 || fft_size < 2 || (fft_size & 1) || hop < 1 || iters < 0) return ST_BADARG;
+    if (T == 0) return ST_OK;
+    if (!mag || !x || !workspace || ldm < fft_size / 2 + 1) return ST_BADARG;
+    if (workspace_bytes < gl_workspace_bytes(T, fft_size, hop, iters)) return ST_WORKSPACE;
+    return (int)gl_run(static_cast<const double*>(mag), ldm, T, fft_size, hop, iters, static_cast<double*>(x),
+                       workspace, rmse_out, reinterpret_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

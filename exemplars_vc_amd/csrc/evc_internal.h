@@ -161,4 +161,9 @@ hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttS
                          int iters, int first, int write_err, double* err2, int eps_mode, double eps,
                          double l1, int c_req, int all_live_known, int loss, hipStream_t s);
 
+// ----- evc_gl.hip -----
+size_t gl_workspace_bytes(int T_, int F, int hop, int iters);
+hipError_t gl_run(const double* mag, long ldm, int T_, int F, int hop, int iters, double* x, void* ws,
+                  double* rmse_host, hipStream_t s);
+
 }  // namespace evc

@@ -290,3 +290,36 @@ def frame_residuals(A, X, H, *, layout="bin_major", dtype=None, device=None):
     _lib.check(st, "evc_residual")
     err2 = err2[:T]
     return err2.cpu().numpy() if x_np else err2
+
+
+def griffin_lim(magnitude_spectrogram, fft_size, hopsamp, iterations, x0, *, device=None, want_rmse=False):
+    """Griffin-Lim reconstruction on the GPU (float64): magnitudes (T, fft_size/2+1) with rows as time
+    slices and the initial signal x0 (T*hopsamp + fft_size samples) -> reconstructed signal
+    [, per-iteration RMSE].  Mirrors zz_audio_utilities.reconstruct_signal_griffin_lim."""
+    torch = _torch()
+    device = require_device(device)
+    L = _lib.lib()
+    mag, m_np = _to_dev(magnitude_spectrogram, torch.float64, device)
+    T, nb = mag.shape
+    fft_size, hopsamp, iterations = int(fft_size), int(hopsamp), int(iterations)
+    if nb != fft_size // 2 + 1:
+        raise ValueError(f"expected {fft_size // 2 + 1} frequency bins for fft_size={fft_size}, got {nb}")
+    n = T * hopsamp + fft_size
+    was_np = not isinstance(x0, torch.Tensor)
+    x = torch.as_tensor(np.asarray(x0, dtype=np.float64) if was_np else x0, dtype=torch.float64).to(device).clone()
+    if x.numel() != n:
+        raise ValueError(f"x0 must have {n} samples, got {x.numel()}")
+    ws_bytes = int(L.evc_griffin_lim_workspace_bytes(T, fft_size, hopsamp, iterations))
+    if ws_bytes == 0:
+        raise ValueError("unsupported Griffin-Lim configuration (fft_size must be even and >= 2)")
+    ws = _workspace(ws_bytes, device)
+    rmse = np.zeros(max(iterations, 1)) if want_rmse else None
+    with torch.cuda.device(device):
+        stream = torch.cuda.current_stream(device).cuda_stream
+        st = L.evc_griffin_lim(mag.data_ptr(), _ld(mag), T, fft_size, hopsamp, iterations, x.data_ptr(),
+                               ws.data_ptr(), ws.numel(),
+                               rmse.ctypes.data_as(C.POINTER(C.c_double)) if want_rmse else None,
+                               C.c_void_p(stream))
+    _lib.check(st, "evc_griffin_lim")
+    out = x.cpu().numpy() if (m_np and was_np) else x
+    return (out, rmse[:iterations]) if want_rmse else out

@@ -13,6 +13,7 @@
  *                     - nmf_tool NMF.NMF (mu, initW)    nmf_tool/nmf.py:36-40,57-67
  *   evc_synthesize  replaces np.matmul(H.T, B) in convert()  04_align_n_nmf.py:371-373,391
  *   evc_nmf_convert both of the above back to back (factorize() + convert(), :452-455)
+ *   evc_griffin_lim replaces reconstruct_signal_griffin_lim()  zz_audio_utilities.py:258-292
  *   evc_residual    replaces sklearn _beta_divergence(beta=2, square_root=True)
  *                   (_nmf.py:85-135) and pymf frobenius_norm (pymf/base.py:144-165)
  *
@@ -169,6 +170,19 @@ int evc_residual(const void* A, int lda, const void* X, int ldx, const void* H, 
                  int M, int N, int T, int layout, int dtype,
                  double* err2_out, void* workspace, size_t workspace_bytes,
                  evc_stream_t stream);
+
+/* Griffin-Lim phase reconstruction - the back end that follows the path when the scripts run on
+ * STFT magnitudes: reconstruct_signal_griffin_lim(), zz_audio_utilities.py:258-292 (with its
+ * stft_for_reconstruction / istft_for_reconstruction, :181-218), called from synthesize2(),
+ * 04_align_n_nmf.py:182-191.  float64.
+ *   mag : T x (fft_size/2 + 1) magnitudes, rows are time slices, row stride ldm (device)
+ *   x   : T*hop + fft_size samples (device); in: the initial signal (the reference draws
+ *         np.random.randn), out: the reconstruction after `iters` iterations
+ *   rmse_out (host, iters doubles or NULL): the per-iteration RMSE the reference prints; non-NULL
+ *         makes the call synchronous.   fft_size must be even. */
+size_t evc_griffin_lim_workspace_bytes(int T, int fft_size, int hop, int iters);
+int evc_griffin_lim(const void* mag, int ldm, int T, int fft_size, int hop, int iters, void* x,
+                    void* workspace, size_t workspace_bytes, double* rmse_out, evc_stream_t stream);
 
 #ifdef __cplusplus
 }

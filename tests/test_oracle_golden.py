@@ -94,3 +94,12 @@ def test_mu_monotone_and_nonnegative():
         cur = o.residual_fro(p["A"], p["X"], H)
         assert cur <= prev * (1 + 1e-12) and (H >= 0).all()
         prev = cur
+
+
+@pytest.mark.parametrize("path", golden_files("gl_"), ids=os.path.basename)
+def test_griffin_lim_restatement_is_bit_exact(path):
+    """vectors produced by the reference's own zz_audio_utilities.py."""
+    g = load_golden(path)
+    x, rmse = o.griffin_lim(g["mag"], int(g["n_fft"]), int(g["hop"]), int(g["iters"]), g["x0"])
+    assert np.array_equal(x, g["x"])
+    np.testing.assert_allclose(rmse, g["rmse"], rtol=1e-12)     # the reference prints repr-rounded floats

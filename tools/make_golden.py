@@ -161,8 +161,35 @@ def audio_case():
     sklearn_case("sklearn_audio_stft", 201, 160, 40, 0, tol=1e-4, A=A, B=B, X=X)
 
 
+def griffin_lim_cases():
+    """the reference's own Griffin-Lim (zz_audio_utilities.py, numpy + `from pylab
+    import *`; matplotlib is installed here) on magnitude spectrograms of its sample audio."""
+    import contextlib
+    import io
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    sys.path.insert(0, REF)
+    with contextlib.redirect_stdout(io.StringIO()):
+        import zz_audio_utilities as zz
+    pcm = read_wav(os.path.join(REF, "data/SF1/100002.wav"))
+    for name, sl, n_fft, hop, iters, seed in [("gl_t96_fft400_hop80_k25", slice(60, 156), 400, 80, 25, 11),
+                                              ("gl_t50_fft256_hop64_k40", slice(100, 150), 256, 64, 40, 12),
+                                              ("gl_t33_fft400_hop80_k3", slice(10, 43), 400, 80, 3, 13)]:
+        mag = np.abs(zz.stft_for_reconstruction(pcm, n_fft, hop))[sl]
+        np.random.seed(seed)
+        st = np.random.get_state()
+        x0 = np.random.randn(int(mag.shape[0] * hop + n_fft))        # what the reference will draw
+        np.random.set_state(st)
+        with contextlib.redirect_stdout(io.StringIO()) as out:
+            x = zz.reconstruct_signal_griffin_lim(mag, n_fft, hop, iters)
+        rmse = np.array([float(l.split("RMSE:")[1]) for l in out.getvalue().splitlines() if "RMSE" in l])
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), surface="griffin_lim", mag=mag, n_fft=n_fft, hop=hop,
+                            iters=iters, x0=x0, x=x, rmse=rmse)
+        print(f"{name}: T={mag.shape[0]} bins={mag.shape[1]} len={len(x)} final rmse={rmse[-1]:.3e}")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    griffin_lim_cases()
     # G1: the live call, fixed 50-iteration budget and the script's default (tol=1e-4, <=150)
     sklearn_case("sklearn_m25_n64_t32_k50", 25, 64, 32, 101, tol=0.0, max_iter=50)
     sklearn_case("sklearn_m201_n128_t40_tol", 201, 128, 40, 102, tol=1e-4)
