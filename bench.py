@@ -73,8 +73,14 @@ def cpu_baseline(M, N, K, seed, budget_frames):
     try:
         import threadpoolctl
         info = threadpoolctl.threadpool_info()
-        out["blas"] = [{"api": i.get("internal_api"), "threads": i.get("num_threads")} for i in info]
-        out["cores"] = max([i.get("num_threads", 1) for i in info] + [1])
+        out["blas"] = [{"api": i.get("internal_api"), "threads": i.get("num_threads"),
+                        "lib": os.path.basename(i.get("filepath", ""))} for i in info]
+        # the threads the timed numpy GEMMs actually ran on: numpy's own BLAS pool
+        mine = [i for i in info if i.get("user_api") == "blas" and "numpy" in i.get("filepath", "")]
+        if not mine:
+            mine = [i for i in info if i.get("user_api") == "blas"]
+        if mine:
+            out["cores"] = int(mine[0].get("num_threads", 1))
     except Exception:
         pass
     # pymf-literal (Gram and numerator recomputed per iteration) on a quarter of the frames

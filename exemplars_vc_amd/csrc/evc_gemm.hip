@@ -161,6 +161,8 @@ hipError_t gemm_nt(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int 
     if (I <= 0 || J <= 0) return hipSuccess;
     if (I % 128 || J % 64 || Kd % KS || Kd <= 0) return hipErrorInvalidValue;
     MuEpilogue<T> ep{};
+    // few output tiles (one utterance): 64x64 tiles put 2-4x more workgroups on the 256 CUs
+    if ((long)(I / 128) * (J / 64) < 256) return launch_nt<T, 64, 64, 32, 32, false>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s);
     if (J % 128 == 0) return launch_nt<T, 128, 128, 64, 32, false>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s);
     return launch_nt<T, 128, 64, 32, 32, false>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s);
 }
