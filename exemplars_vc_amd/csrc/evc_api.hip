@@ -40,6 +40,8 @@ Dims make_dims(int M, int N, int T_, int n_utt, int Mb = 0) {
 template <typename T> struct Workspace {
     T *At, *Am, *Xt, *H0, *H1, *Pt, *G, *Vt;
     T *Akl, *Rt;         // KL: dictionary / column sums, and X / max(V, eps)
+    T* Vsplit;           // split-K slabs of V = H Am^T when there are few frames
+    size_t vsplit_elems;
     double* err2;
     UttState u;
     FusedLayout fl;
@@ -72,6 +74,8 @@ Workspace<T> carve(void* base, const Dims& d, int algo, int n_slots, bool fused)
     w.H0 = need_h0 ? c.take<T>((size_t)d.Tp * d.Np) : nullptr;
     w.Pt = fused ? nullptr : c.take<T>((size_t)d.Tp * d.Np);
     w.Vt = fused ? nullptr : c.take<T>((size_t)d.Tp * d.Mj);
+    w.vsplit_elems = (!fused && d.Tp <= 2048) ? (size_t)8 * d.Tp * d.Mj : 0;
+    w.Vsplit = w.vsplit_elems ? c.take<T>(w.vsplit_elems) : nullptr;
     w.fl = FusedLayout{};
     w.fb = FusedBuffers{};
     if (fused) {
@@ -278,7 +282,7 @@ int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int 
     bool v_valid = false;
 
     auto residual_check = [&](int c) -> int {
-        if (!v_valid) HIP_TRY(gemm_nt<T>(Hc, d.Np, w.Am, d.Np, w.Vt, d.Mj, d.Tp, d.Mj, d.Np, s));
+        if (!v_valid) HIP_TRY(gemm_nt<T>(Hc, d.Np, w.Am, d.Np, w.Vt, d.Mj, d.Tp, d.Mj, d.Np, s, w.Vsplit, w.vsplit_elems));
         v_valid = true;
         if (kl) HIP_TRY(frame_err_kl<T>(w.Xt, d.Mk, w.Vt, d.Mj, M, T_, o.eps, w.err2, s));
         else HIP_TRY(frame_err2<T>(w.Xt, d.Mk, w.Vt, d.Mj, M, T_, w.err2, s));
@@ -306,7 +310,7 @@ int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int 
             HIP_TRY(gemm_nt_mu<T>(Hc, d.Np, w.G, d.Np, Hn, d.Tp, d.Np, d.Np, ep, s));
             T* tmp = Hc; Hc = Hn; Hn = tmp;
         } else {
-            if (!v_valid) HIP_TRY(gemm_nt<T>(Hc, d.Np, w.Am, d.Np, w.Vt, d.Mj, d.Tp, d.Mj, d.Np, s));
+            if (!v_valid) HIP_TRY(gemm_nt<T>(Hc, d.Np, w.Am, d.Np, w.Vt, d.Mj, d.Tp, d.Mj, d.Np, s, w.Vsplit, w.vsplit_elems));
             ep.Hin = Hc;
             if (kl) {                     // H' = H (.) (X (/) max(V, eps)) (A / colsum)   sklearn _nmf.py:556-606
                 HIP_TRY(kl_ratio<T>(w.Xt, d.Mk, w.Vt, d.Mj, M, d.Tp, o.eps, w.Rt, d.Mk, s));

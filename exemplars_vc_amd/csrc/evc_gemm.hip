@@ -25,7 +25,11 @@ template <typename T, int E> struct VecOf { typedef T type __attribute__((ext_ve
 template <typename T, int BM, int BN, int WM, int WN, bool MU>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_gemm_nt(
     const T* __restrict__ L, int ldl, const T* __restrict__ R, int ldr, T* __restrict__ C, int ldc,
-    int Kd, MuEpilogue<T> ep) {
+    int Kd, MuEpilogue<T> ep, long slab) {
+    // split-K: blockIdx.z owns k in [z Kd, (z+1) Kd) and writes its partial product to slab z
+    L += (long)blockIdx.z * Kd;
+    R += (long)blockIdx.z * Kd;
+    C += (long)blockIdx.z * slab;
     constexpr int NWN = BN / WN;
     constexpr int NTHR = (BM / WM) * NWN * 64;
     constexpr int MI = WM / 16, NI = WN / 16;
@@ -148,21 +152,48 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_gemm_nt(
 
 template <typename T, int BM, int BN, int WM, int WN, bool MU>
 static hipError_t launch_nt(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int I, int J,
-                            int Kd, const MuEpilogue<T>& ep, hipStream_t s) {
-    dim3 grid(J / BN, I / BM), block((BM / WM) * (BN / WN) * 64);
+                            int Kd, const MuEpilogue<T>& ep, hipStream_t s, int splits = 1, long slab = 0) {
+    dim3 grid(J / BN, I / BM, splits), block((BM / WM) * (BN / WN) * 64);
     hipLaunchKernelGGL((k_gemm_nt<T, BM, BN, WM, WN, MU>), grid, block, 0, s, L, ldl, R, ldr, C, ldc,
-                       Kd, ep);
+                       Kd / splits, ep, slab);
     return hipGetLastError();
+}
+
+// C = sum_z part[z]   (fixed order: bitwise reproducible)
+template <typename T>
+__global__ __launch_bounds__(256) void k_sum_slabs(const T* __restrict__ part, long slab, int splits, long n,
+                                                   T* __restrict__ C) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    T acc = part[i];
+    for (int z = 1; z < splits; ++z) acc += part[z * slab + i];
+    C[i] = acc;
 }
 
 template <typename T>
 hipError_t gemm_nt(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int I, int J, int Kd,
-                   hipStream_t s) {
+                   hipStream_t s, T* scratch, size_t scratch_elems) {
     if (I <= 0 || J <= 0) return hipSuccess;
     if (I % 128 || J % 64 || Kd % KS || Kd <= 0) return hipErrorInvalidValue;
     MuEpilogue<T> ep{};
-    // few output tiles (one utterance): 64x64 tiles put 2-4x more workgroups on the 256 CUs
-    if ((long)(I / 128) * (J / 64) < 256) return launch_nt<T, 64, 64, 32, 32, false>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s);
+    // few output tiles (one utterance): 64x64 tiles put 2-4x more workgroups on the 256 CUs, and a long
+    // contraction is additionally split over blockIdx.z into slabs of partial products (summed in order)
+    const long blocks = (long)(I / 64) * (J / 64);
+    if ((long)(I / 128) * (J / 64) < 256) {
+        int splits = 1;
+        const long slab = (long)I * ldc;
+        if (scratch && ldc == J) {
+            while (splits < 8 && blocks * splits * 2 <= 512 && (Kd / (splits * 2)) % KS == 0 && Kd / (splits * 2) >= 512 &&
+                   (size_t)(splits * 2) * slab <= scratch_elems)
+                splits *= 2;
+        }
+        if (splits == 1) return launch_nt<T, 64, 64, 32, 32, false>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s);
+        hipError_t e = launch_nt<T, 64, 64, 32, 32, false>(L, ldl, R, ldr, scratch, ldc, I, J, Kd, ep, s, splits, slab);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL((k_sum_slabs<T>), dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, s, scratch, slab, splits,
+                           slab, C);
+        return hipGetLastError();
+    }
     if (J % 128 == 0) return launch_nt<T, 128, 128, 64, 32, false>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s);
     return launch_nt<T, 128, 64, 32, 32, false>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s);
 }
@@ -240,7 +271,7 @@ hipError_t gemm_strided(const T* L, long lsi, long lsk, const T* R, long rsj, lo
 }
 
 #define EVC_INST(T)                                                                                  \
-    template hipError_t gemm_nt<T>(const T*, int, const T*, int, T*, int, int, int, int, hipStream_t); \
+    template hipError_t gemm_nt<T>(const T*, int, const T*, int, T*, int, int, int, int, hipStream_t, T*, size_t); \
     template hipError_t gemm_nt_mu<T>(const T*, int, const T*, int, T*, int, int, int,                \
                                       const MuEpilogue<T>&, hipStream_t);                            \
     template hipError_t gemm_strided<T>(const T*, long, long, const T*, long, long, T*, long, long,  \

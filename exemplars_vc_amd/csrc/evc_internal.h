@@ -82,9 +82,10 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 // ----- evc_gemm.hip -----
 // C[I x J] = L[I x Kd] * R[J x Kd]^T, all row-major, I % 128 == 0, J % 64 == 0, Kd % 16 == 0.
+// scratch (optional, scratch_elems elements): lets a small-grid, long-K product be split over K.
 template <typename T>
 hipError_t gemm_nt(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int I, int J, int Kd,
-                   hipStream_t s);
+                   hipStream_t s, T* scratch = nullptr, size_t scratch_elems = 0);
 // Same contraction with the multiplicative update as epilogue: C = mu(Hin, P, L R^T).
 template <typename T>
 hipError_t gemm_nt_mu(const T* L, int ldl, const T* R, int ldr, T* Hout, int I, int J, int Kd,
