@@ -93,9 +93,62 @@ def factorize_utterances(X_list, W, tol=1e-4, *, device=None, algo="auto", max_i
     return [act[offs[i]:offs[i + 1]].T for i in range(len(X_list))], info["n_iter"]
 
 
-def convert(H, B, *, device=None):
-    """Converted spectrogram np.matmul(H.T, B): H (N x T) as returned by `_factorize`,
-    B (N x Mb) target exemplars as rows -> (T x Mb).  04_align_n_nmf.py:391."""
+def synthesize_rows(H, B, *, device=None):
+    """np.matmul(H.T, B): H (N x T) as returned by `_factorize`, B (N x Mb) target exemplars as rows
+    -> (T x Mb).  04_align_n_nmf.py:371-373,391."""
     H = np.asarray(H)
     B = np.asarray(B)
     return synthesize(B, np.ascontiguousarray(H.T), layout="frame_major", device=device)
+
+
+def _stack(feats, key, transform=None):
+    """`A = []; for f in feats: A.extend(f[key]); np.asarray(A)` (04_align_n_nmf.py:230-246,320-324):
+    the aligned exemplar frames of every file, one after the other."""
+    rows = [np.asarray(f[key]) if transform is None else transform(np.asarray(f[key])) for f in feats]
+    rows = [r[:, np.newaxis] if r.ndim == 1 else r for r in rows]
+    return np.concatenate(rows, axis=0)
+
+
+def factorize(tobe_converted, src_feat, *, use_stft=True, tol=1e-4, device=None):
+    """`factorize(tobe_converted, src_feat)` of 04_align_n_nmf.py:218-333: stack the aligned source
+    exemplars into the dictionary, solve the activations of the utterance to convert (one solve per
+    feature stream), and - WORLD branch - form the reference's residual.
+
+    use_stft mirrors the script's module-level flag (config/config:12).
+      use_stft=True : tobe_converted['real'] (T x 201), src_feat[i]['real'] -> ({'H_stft': N x T}, None)
+      use_stft=False: 'sp', 'ap' (T x 513) and 'f0' (T,) -> ({'H_sp','H_ap','H_f0'}, {'r_sp','r_ap','r_f0'})
+    The residual is the reference's literal expression np.log(H.T @ A - conv) (:292-294), which is NaN
+    wherever the reconstruction undershoots; it is reproduced, not repaired.  The reference's pickle
+    cache (keyed by the NUMBER of dictionary files only, so it returns a stale H for a different
+    utterance) is deliberately not reproduced.
+    """
+    if use_stft:
+        conv_stft = np.abs(np.asarray(tobe_converted["real"]))
+        A_stft = _stack(src_feat, "real", np.abs)
+        return {"H_stft": _factorize(conv_stft, A_stft, tol=tol, device=device)}, None
+    streams = {"sp": (np.asarray(tobe_converted["sp"]), _stack(src_feat, "sp")),
+               "ap": (np.asarray(tobe_converted["ap"]), _stack(src_feat, "ap")),
+               "f0": (np.asarray(tobe_converted["f0"])[:, np.newaxis], _stack(src_feat, "f0"))}
+    H, R = {}, {}
+    for name, (conv, A) in streams.items():
+        H["H_" + name] = _factorize(conv, A, tol=tol, device=device)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            R["r_" + name] = np.log(synthesize_rows(H["H_" + name], A, device=device) - conv)
+    return H, R
+
+
+def convert(H, tar_feat, residual=None, *, use_stft=True, device=None):
+    """`convert(H, tar_feat, residual)` of 04_align_n_nmf.py:336-393: stack the parallel target
+    exemplars and synthesise H.T @ B per stream; the WORLD branch applies the reference's residual
+    expression exp(log(H.T @ B) + log(r)) with NaNs of r zeroed first (:367-373), literally."""
+    if use_stft:
+        return synthesize_rows(H["H_stft"], _stack(tar_feat, "real", np.abs), device=device)
+    out = {}
+    for name in ("sp", "ap", "f0"):
+        B = _stack(tar_feat, name)
+        r = np.array(residual["r_" + name], copy=True)
+        r[np.isnan(r)] = 0
+        with np.errstate(invalid="ignore", divide="ignore"):
+            out[name] = np.exp(np.log(synthesize_rows(H["H_" + name], B, device=device)) + np.log(r))
+    out["f0"] = np.squeeze(out["f0"])
+    return out

@@ -71,14 +71,14 @@ def test_sklearn_golden_solver(path, algo):
                                   and "zero" not in p], ids=os.path.basename)
 def test_factorize_surface(path):
     """The drop-in `_factorize(X, W, beta_loss, tol)` / `convert` pair."""
-    from exemplars_vc_amd.compat.factorize import _factorize, convert
+    from exemplars_vc_amd.compat.factorize import _factorize, synthesize_rows
     g = load_golden(path)
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         H = _factorize(g["X_rows"], g["W_rows"], tol=float(g["tol"]))
     assert H.shape == g["H"].shape
     assert_close64(H, g["H"], "H")
-    assert_close64(convert(H, g["B_rows"]), g["Y_rows"], "Y")
+    assert_close64(synthesize_rows(H, g["B_rows"]), g["Y_rows"], "Y")
 
 
 # ----------------------------------------------------------------------------------------
@@ -415,3 +415,59 @@ def test_c3_and_c5_shapes_smoke():
         want = o.mu_solve(p["A"], p["X"][:, :16], np.full((N, 16), 0.01), K, eps_mode=o.EPS_ZERO_REPLACE,
                           eps=o.SK_EPSILON, l1=l1)
         assert_close64(H[:, :16], want, f"slice M={M} N={N}")
+
+
+# ----------------------------------------------------------------------------------------
+# factorize(tobe_converted, src_feat) / convert(H, tar_feat, residual): stacking + streams (rows a-9, a-10)
+# ----------------------------------------------------------------------------------------
+def _feature_files(rng, n_files, bins, frames):
+    feats = []
+    for T in frames[:n_files]:
+        f = {}
+        for k, m in bins.items():
+            v = rng.random((T, m)) ** 2 + 1e-3
+            f[k] = v[:, 0] if m == 1 and k == "f0" else v
+        feats.append(f)
+    return feats
+
+
+@pytest.mark.parametrize("use_stft", [True, False])
+def test_factorize_and_convert_feature_level(use_stft):
+    import warnings
+    from exemplars_vc_amd.compat.factorize import factorize, convert
+    o = oracle()
+    rng = np.random.default_rng(12)
+    if use_stft:
+        bins = {"real": 201}
+        src = _feature_files(rng, 3, bins, [30, 41, 25])
+        tar = _feature_files(rng, 3, bins, [30, 41, 25])
+        for f in src + tar:
+            f["real"] = f["real"] * np.sign(rng.standard_normal(f["real"].shape))     # |.| is applied by the path
+        conv = {"real": _feature_files(rng, 1, bins, [37])[0]["real"]}
+    else:
+        bins = {"sp": 65, "ap": 65, "f0": 1}
+        src = _feature_files(rng, 3, bins, [30, 41, 25])
+        tar = _feature_files(rng, 3, bins, [30, 41, 25])
+        conv = _feature_files(rng, 1, bins, [37])[0]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        H, R = factorize(conv, src, use_stft=use_stft, tol=1e-3)
+        out = convert(H, tar, R, use_stft=use_stft)
+        Hw, Rw = o.s_factorize_features(conv, src, use_stft, tol=1e-3)
+        outw = o.s_convert_features(Hw, tar, Rw, use_stft)
+    for k in Hw:
+        assert H[k].shape == Hw[k].shape
+        assert_close64(H[k], Hw[k], k)
+    if use_stft:
+        assert R is None and out.shape == (37, 201)
+        assert_close64(out, outw, "converted stft")
+    else:
+        for k in Rw:
+            # the reference's residual log(H.T A - conv) is NaN wherever the reconstruction undershoots; where
+            # the fit is exact to rounding (the one-bin f0 stream) that sign is rounding noise, so the
+            # comparison is made on exp(r) = H.T A - conv, ignoring differences below 1e-10 of the data scale
+            scale = float(np.max(np.abs(np.asarray(conv[k[2:]]))))
+            dg = np.where(np.isnan(R[k]), 0.0, np.exp(R[k]))
+            dw = np.where(np.isnan(Rw[k]), 0.0, np.exp(Rw[k]))
+            np.testing.assert_allclose(dg, dw, rtol=1e-6, atol=1e-10 * scale)
+        assert set(out) == {"sp", "ap", "f0"} and out["f0"].shape == (37,)
