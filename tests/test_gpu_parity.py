@@ -471,3 +471,28 @@ def test_factorize_and_convert_feature_level(use_stft):
             dw = np.where(np.isnan(Rw[k]), 0.0, np.exp(Rw[k]))
             np.testing.assert_allclose(dg, dw, rtol=1e-6, atol=1e-10 * scale)
         assert set(out) == {"sp", "ap", "f0"} and out["f0"].shape == (37,)
+
+
+def test_degenerate_sizes_and_empty_utterances():
+    import exemplars_vc_amd as evc
+    o = oracle()
+    # one bin, one exemplar, one frame
+    A, X, H0 = np.array([[2.0]]), np.array([[3.0]]), np.array([[0.7]])
+    for algo in VARIANTS:
+        got = evc.solve_activations(A, X, H0, iters=9, **variant_kw(algo))
+        assert_close64(got, o.mu_solve(A, X, H0, 9), algo)
+    # a batch with empty utterances in it (first, middle, last)
+    p = o.synth_problem(25, 64, 50, seed=77)
+    X_rows, W_rows = np.ascontiguousarray(p["X"].T), np.ascontiguousarray(p["A"].T)
+    offs = [0, 0, 20, 20, 50, 50]
+    act, info = evc.solve_activations(W_rows, X_rows, layout="frame_major", iters=30, eps_mode="zero_replace",
+                                      init="sklearn", check_every=10, stop_rule="sklearn", tol=1e-3,
+                                      utt_offsets=offs, info=True)
+    for (a, b), ni in zip([(0, 20), (20, 50)], [info["n_iter"][1], info["n_iter"][3]]):
+        want, n, _ = o.sklearn_mu_fixed_dictionary(X_rows[a:b], W_rows, 30, 1e-3)
+        assert n == ni
+        assert_close64(act[a:b], want, "utterance")
+    assert np.all(np.isnan(info["err"][[0, 2, 4]]))
+    # no frames at all
+    e = evc.solve_activations(W_rows, X_rows[:0], layout="frame_major", iters=5, init="sklearn")
+    assert e.shape == (0, 64)
