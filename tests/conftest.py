@@ -13,6 +13,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the library is built in-tree by __graft_entry__.build(); a checkout without it (fresh clone) gets it
+    # compiled here once (hipcc cross-compiles without a GPU).  The product itself never builds implicitly.
+    from exemplars_vc_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        from exemplars_vc_amd.csrc.build import build
+        build()
 
 
 def _has_gpu():
