@@ -496,3 +496,21 @@ def test_degenerate_sizes_and_empty_utterances():
     # no frames at all
     e = evc.solve_activations(W_rows, X_rows[:0], layout="frame_major", iters=5, init="sklearn")
     assert e.shape == (0, 64)
+
+
+def test_float32_factorize_surface():
+    """float32 inputs keep their dtype through `_factorize`, as they do through scikit-learn (check_array
+    keeps float32); compared with the float32 oracle run.  Tolerance: float32 trajectories of different
+    summation orders drift apart at ~K*sqrt(N)*6e-8, hence rtol 5e-3 with an absolute floor of 1e-5*max|H|."""
+    import warnings
+    from exemplars_vc_amd.compat.factorize import _factorize
+    o = oracle()
+    p = o.synth_problem(40, 96, 60, seed=21)
+    X = np.ascontiguousarray(p["X"].T).astype(np.float32)
+    W = np.ascontiguousarray(p["A"].T).astype(np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        H = _factorize(X, W, tol=0.0)
+    want, n, _ = o.sklearn_mu_fixed_dictionary(X, W, 150, 0.0)
+    assert H.dtype == np.float32 and want.dtype == np.float32
+    np.testing.assert_allclose(H, want.T, rtol=5e-3, atol=1e-5 * float(want.max()))
