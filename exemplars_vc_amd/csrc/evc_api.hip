@@ -516,4 +516,28 @@ int evc_griffin_lim(const void* mag, int ldm, int T, int fft_size, int hop, int 
                        workspace, rmse_out, reinterpret_cast<hipStream_t>(stream));
 }
 
+static bool dtw_offsets_ok(const int* off, int n_pairs) {
+    if (!off || off[0] != 0) return false;
+    for (int p = 0; p < n_pairs; ++p)
+        if (off[p + 1] < off[p] || off[p + 1] - off[p] > dtw_max_frames()) return false;
+    return true;
+}
+
+size_t evc_dtw_workspace_bytes(const int* a_offsets, const int* b_offsets, int n_pairs) {
+    if (n_pairs < 1 || !dtw_offsets_ok(a_offsets, n_pairs) || !dtw_offsets_ok(b_offsets, n_pairs)) return 0;
+    return dtw_workspace_bytes(a_offsets, b_offsets, n_pairs);
+}
+
+int evc_dtw_align(const void* A, int lda, const int* a_offsets, const void* B, int ldb,
+                  const int* b_offsets, int D, int n_pairs, int* path_a, int* path_b, int* path_len,
+                  double* total, void* workspace, size_t workspace_bytes, evc_stream_t stream) {
+    if (n_pairs < 1 || D < 1 || lda < D || ldb < D) return ST_BADARG;
+    if (!dtw_offsets_ok(a_offsets, n_pairs) || !dtw_offsets_ok(b_offsets, n_pairs)) return ST_BADARG;
+    if (!A || !B || !path_a || !path_b || !path_len || !workspace) return ST_BADARG;
+    if (workspace_bytes < dtw_workspace_bytes(a_offsets, b_offsets, n_pairs)) return ST_WORKSPACE;
+    return (int)dtw_run(static_cast<const double*>(A), lda, a_offsets, static_cast<const double*>(B), ldb,
+                        b_offsets, D, n_pairs, path_a, path_b, path_len, total, workspace,
+                        reinterpret_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

@@ -1,0 +1,173 @@
+// Dynamic-time-warping alignment of parallel utterance pairs: the step that builds the
+// parallel exemplar dictionary before the activation solve - _dtw_alignment(), 01_make_dict_parallel.py:
+// 215-228, which calls the third-party `dtw` package with a squared-Euclidean frame distance.
+//
+// One workgroup per utterance pair (the corpus is 162 pairs: one round on the 256 CUs):
+//   k_dtw_cost        C[i][j] = sum_d (a[i][d] - b[j][d])^2, summed left to right without FMA contraction,
+//                     exactly the arithmetic of `sum(np.square(x - y))`
+//   k_dtw_accumulate  D[i][j] = C[i][j] + min(D[i-1][j-1], D[i][j-1], D[i-1][j]) by anti-diagonal wavefront
+//                     (cells of one anti-diagonal are independent); the three live diagonals are kept in
+//                     LDS, the full matrix goes to HBM for the trace-back, which follows the package's
+//                     rule: argmin over (diagonal, i-1, j-1), first minimum wins.
+// Integer/index work: results are bit-exact against the restated algorithm (oracle.dtw_align); PARITY
+// with the package itself is UNPINNED (not installable here, no alignment fixture in the reference).
+#include "evc_internal.h"
+
+namespace evc {
+
+struct DtwArgs {
+    const double* A; long lda;
+    const double* B; long ldb;
+    const int* aoff;        // [n_pairs+1] frame offsets into A
+    const int* boff;        // [n_pairs+1]
+    const long* doff;       // [n_pairs+1] element offsets of the accumulated-cost matrices
+    double* Dm;
+    int* path_a; int* path_b; int* path_len; double* total;
+    int D;
+};
+
+__global__ __launch_bounds__(256) void k_dtw_cost(DtwArgs g) {
+#pragma clang fp contract(off)
+    const int pair = blockIdx.y;
+    const int Ta = g.aoff[pair + 1] - g.aoff[pair], Tb = g.boff[pair + 1] - g.boff[pair];
+    const long cell = (long)blockIdx.x * 256 + threadIdx.x;
+    if (cell >= (long)Ta * Tb) return;
+    const int i = (int)(cell / Tb), j = (int)(cell % Tb);
+    const double* a = g.A + (long)(g.aoff[pair] + i) * g.lda;
+    const double* b = g.B + (long)(g.boff[pair] + j) * g.ldb;
+    double acc = 0.0;
+    for (int d = 0; d < g.D; ++d) {
+        const double df = a[d] - b[d];
+        const double sq = df * df;
+        acc = acc + sq;
+    }
+    g.Dm[g.doff[pair] + cell] = acc;
+}
+
+constexpr int DTW_THREADS = 1024;
+
+__global__ __launch_bounds__(DTW_THREADS) void k_dtw_accumulate(DtwArgs g) {
+    extern __shared__ double diag[];        // 3 x (Ta + 1): rolling anti-diagonals, indexed by i + 1
+    const int pair = blockIdx.x;
+    const int Ta = g.aoff[pair + 1] - g.aoff[pair], Tb = g.boff[pair + 1] - g.boff[pair];
+    const int tid = threadIdx.x;
+    const long pbase = (long)g.aoff[pair] + g.boff[pair];   // path buffers: capacity Ta + Tb per pair
+    if (Ta <= 0 || Tb <= 0) {
+        if (tid == 0) { g.path_len[pair] = 0; if (g.total) g.total[pair] = 0.0; }
+        return;
+    }
+    double* Dm = g.Dm + g.doff[pair];
+    const double inf = __longlong_as_double(0x7ff0000000000000LL);
+    const int W = Ta + 1;
+    double* d0 = diag;            // diagonal k
+    double* d1 = diag + W;        // diagonal k-1
+    double* d2 = diag + 2 * W;    // diagonal k-2
+    for (int i = tid; i < 3 * W; i += DTW_THREADS) diag[i] = inf;
+    __syncthreads();
+    for (int k = 0; k <= Ta + Tb - 2; ++k) {
+        const int ilo = k - (Tb - 1) > 0 ? k - (Tb - 1) : 0;
+        const int ihi = k < Ta - 1 ? k : Ta - 1;
+        for (int i = ilo + tid; i <= ihi; i += DTW_THREADS) {
+            const int j = k - i;
+            // slot i+1 of a diagonal holds D[i][.]; slot 0 is the inf border; D0[0][0] = 0 for the first cell
+            const double dg = (i == 0 && j == 0) ? 0.0 : ((i > 0 && j > 0) ? d2[i] : inf);
+            const double lf = j > 0 ? d1[i + 1] : inf;      // D[i][j-1]
+            const double up = i > 0 ? d1[i] : inf;          // D[i-1][j]
+            double m = dg < lf ? dg : lf;                   // min(D0[i,j], D0[i+1,j], D0[i,j+1])
+            m = m < up ? m : up;
+            const double v = Dm[(long)i * Tb + j] + m;
+            d0[i + 1] = v;
+            Dm[(long)i * Tb + j] = v;
+        }
+        __syncthreads();
+        double* t = d2; d2 = d1; d1 = d0; d0 = t;           // rotate: the oldest diagonal is overwritten next
+        // cells of the recycled buffer outside the next diagonal's range must read as "no cell": the
+        // range test in dg/lf/up above already guards them, so no clearing is needed
+    }
+    // trace-back (dtw package _traceback): one lane walks the path backwards into the end of the buffer
+    __shared__ int s_start;
+    const int cap = Ta + Tb;
+    int* pa = g.path_a + pbase;
+    int* pb = g.path_b + pbase;
+    if (tid == 0) {
+        int i = Ta - 1, j = Tb - 1, pos = cap - 1;
+        pa[pos] = i; pb[pos] = j;
+        while (i > 0 || j > 0) {
+            const double dg = (i > 0 && j > 0) ? Dm[(long)(i - 1) * Tb + (j - 1)] : inf;   // D0[i, j]
+            const double up = i > 0 ? Dm[(long)(i - 1) * Tb + j] : inf;                     // D0[i, j+1]
+            const double lf = j > 0 ? Dm[(long)i * Tb + (j - 1)] : inf;                     // D0[i+1, j]
+            int tb = 0;
+            double m = dg;
+            if (up < m) { m = up; tb = 1; }
+            if (lf < m) { m = lf; tb = 2; }
+            if (tb == 0) { --i; --j; } else if (tb == 1) { --i; } else { --j; }
+            --pos;
+            pa[pos] = i; pb[pos] = j;
+        }
+        s_start = pos;
+        g.path_len[pair] = cap - pos;
+        if (g.total) g.total[pair] = Dm[(long)(Ta - 1) * Tb + (Tb - 1)];
+    }
+    __syncthreads();
+    // move the path to the front of its buffer (ranges overlap: chunked, read - barrier - write)
+    const int start = s_start, len = cap - start;
+    for (int c0 = 0; c0 < len; c0 += DTW_THREADS) {
+        const int e = c0 + tid;
+        int va = 0, vb = 0;
+        if (e < len) { va = pa[start + e]; vb = pb[start + e]; }
+        __syncthreads();
+        if (e < len) { pa[e] = va; pb[e] = vb; }
+        __syncthreads();
+    }
+}
+
+size_t dtw_workspace_bytes(const int* aoff, const int* boff, int n_pairs) {
+    size_t cells = 0;
+    for (int p = 0; p < n_pairs; ++p)
+        cells += (size_t)(aoff[p + 1] - aoff[p]) * (size_t)(boff[p + 1] - boff[p]);
+    return cells * sizeof(double) + (size_t)(n_pairs + 1) * (2 * sizeof(int) + sizeof(long)) + 1024;
+}
+
+int dtw_max_frames() { return (160 * 1024 - 64) / (3 * (int)sizeof(double)) - 1; }   // LDS: 3 diagonals
+
+hipError_t dtw_run(const double* A, long lda, const int* aoff, const double* B, long ldb, const int* boff,
+                   int D, int n_pairs, int* path_a, int* path_b, int* path_len, double* total, void* ws,
+                   hipStream_t s) {
+    char* p = static_cast<char*>(ws);
+    int* d_aoff = reinterpret_cast<int*>(p); p += (((size_t)(n_pairs + 1) * sizeof(int)) + 255) & ~size_t(255);
+    int* d_boff = reinterpret_cast<int*>(p); p += (((size_t)(n_pairs + 1) * sizeof(int)) + 255) & ~size_t(255);
+    long* d_doff = reinterpret_cast<long*>(p); p += (((size_t)(n_pairs + 1) * sizeof(long)) + 255) & ~size_t(255);
+    double* Dm = reinterpret_cast<double*>(p);
+    // element offsets of the per-pair matrices (small, host side)
+    long doff_small[257];
+    long* doff = n_pairs + 1 <= 257 ? doff_small : new long[n_pairs + 1];
+    long maxcells = 0;
+    int maxTa = 0;
+    doff[0] = 0;
+    for (int q = 0; q < n_pairs; ++q) {
+        const long Ta = aoff[q + 1] - aoff[q], Tb = boff[q + 1] - boff[q];
+        doff[q + 1] = doff[q] + Ta * Tb;
+        if (Ta * Tb > maxcells) maxcells = Ta * Tb;
+        if (Ta > maxTa) maxTa = (int)Ta;
+    }
+    hipError_t e = hipMemcpyAsync(d_aoff, aoff, sizeof(int) * (n_pairs + 1), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_boff, boff, sizeof(int) * (n_pairs + 1), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_doff, doff, sizeof(long) * (n_pairs + 1), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);       // `doff` is a host temporary
+    if (doff != doff_small) delete[] doff;
+    if (e != hipSuccess) return e;
+    DtwArgs g{A, lda, B, ldb, d_aoff, d_boff, d_doff, Dm, path_a, path_b, path_len, total, D};
+    if (maxcells > 0) {
+        hipLaunchKernelGGL(k_dtw_cost, dim3((unsigned)((maxcells + 255) / 256), n_pairs), dim3(256), 0, s, g);
+    }
+    const size_t lds = (size_t)3 * (maxTa + 1) * sizeof(double);
+    if (lds > 48 * 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dtw_accumulate),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_dtw_accumulate, dim3(n_pairs), dim3(DTW_THREADS), lds, s, g);
+    return hipGetLastError();
+}
+
+}  // namespace evc

@@ -167,4 +167,11 @@ size_t gl_workspace_bytes(int T_, int F, int hop, int iters);
 hipError_t gl_run(const double* mag, long ldm, int T_, int F, int hop, int iters, double* x, void* ws,
                   double* rmse_host, hipStream_t s);
 
+// ----- evc_dtw.hip -----
+size_t dtw_workspace_bytes(const int* aoff, const int* boff, int n_pairs);
+int dtw_max_frames();
+hipError_t dtw_run(const double* A, long lda, const int* aoff, const double* B, long ldb, const int* boff,
+                   int D, int n_pairs, int* path_a, int* path_b, int* path_len, double* total, void* ws,
+                   hipStream_t s);
+
 }  // namespace evc

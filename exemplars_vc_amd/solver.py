@@ -323,3 +323,45 @@ def griffin_lim(magnitude_spectrogram, fft_size, hopsamp, iterations, x0, *, dev
     _lib.check(st, "evc_griffin_lim")
     out = x.cpu().numpy() if (m_np and was_np) else x
     return (out, rmse[:iterations]) if want_rmse else out
+
+
+def dtw_align(feats_a, feats_b, *, device=None, want_cost=False):
+    """DTW paths of parallel utterance pairs on the GPU.  feats_a[p], feats_b[p]: (frames, features)
+    float64 arrays of pair p.  Returns a list of (path_a, path_b) int arrays [, accumulated costs]:
+    what `dtw.dtw(x, y, dist=lambda u, v: sum(np.square(u - v)))[3]` returns per pair."""
+    torch = _torch()
+    device = require_device(device)
+    L = _lib.lib()
+    feats_a = [np.ascontiguousarray(np.asarray(f, dtype=np.float64)) for f in feats_a]
+    feats_b = [np.ascontiguousarray(np.asarray(f, dtype=np.float64)) for f in feats_b]
+    n = len(feats_a)
+    if n == 0 or len(feats_b) != n:
+        raise ValueError("need the same, non-zero number of utterances on both sides")
+    D = feats_a[0].shape[1]
+    if any(f.ndim != 2 or f.shape[1] != D for f in feats_a + feats_b):
+        raise ValueError("every utterance must be (frames, features) with the same number of features")
+    aoff = np.concatenate([[0], np.cumsum([len(f) for f in feats_a])]).astype(np.int32)
+    boff = np.concatenate([[0], np.cumsum([len(f) for f in feats_b])]).astype(np.int32)
+    A = torch.from_numpy(np.concatenate(feats_a, axis=0)).to(device)
+    B = torch.from_numpy(np.concatenate(feats_b, axis=0)).to(device)
+    ap, bp = aoff.ctypes.data_as(C.POINTER(C.c_int)), boff.ctypes.data_as(C.POINTER(C.c_int))
+    ws_bytes = int(L.evc_dtw_workspace_bytes(ap, bp, n))
+    if ws_bytes == 0:
+        raise ValueError("utterance too long for the DTW kernel's wavefront buffers")
+    ws = _workspace(ws_bytes, device)
+    cap = int(aoff[-1] + boff[-1])
+    pa = torch.empty(max(cap, 1), dtype=torch.int32, device=device)
+    pb = torch.empty(max(cap, 1), dtype=torch.int32, device=device)
+    plen = torch.empty(n, dtype=torch.int32, device=device)
+    tot = torch.empty(n, dtype=torch.float64, device=device)
+    with torch.cuda.device(device):
+        stream = torch.cuda.current_stream(device).cuda_stream
+        st = L.evc_dtw_align(A.data_ptr(), D, ap, B.data_ptr(), D, bp, D, n, pa.data_ptr(), pb.data_ptr(),
+                             plen.data_ptr(), tot.data_ptr(), ws.data_ptr(), ws.numel(), C.c_void_p(stream))
+    _lib.check(st, "evc_dtw_align")
+    pa, pb, plen = pa.cpu().numpy(), pb.cpu().numpy(), plen.cpu().numpy()
+    paths = []
+    for p in range(n):
+        o = int(aoff[p] + boff[p])
+        paths.append((pa[o:o + plen[p]].astype(np.int64), pb[o:o + plen[p]].astype(np.int64)))
+    return (paths, tot.cpu().numpy()) if want_cost else paths

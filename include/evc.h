@@ -14,6 +14,7 @@
  *   evc_synthesize  replaces np.matmul(H.T, B) in convert()  04_align_n_nmf.py:371-373,391
  *   evc_nmf_convert both of the above back to back (factorize() + convert(), :452-455)
  *   evc_griffin_lim replaces reconstruct_signal_griffin_lim()  zz_audio_utilities.py:258-292
+ *   evc_dtw_align   replaces _dtw_alignment() / dtw_alignment()  01_make_dict_parallel.py:215-249
  *   evc_residual    replaces sklearn _beta_divergence(beta=2, square_root=True)
  *                   (_nmf.py:85-135) and pymf frobenius_norm (pymf/base.py:144-165)
  *
@@ -183,6 +184,21 @@ int evc_residual(const void* A, int lda, const void* X, int ldx, const void* H, 
 size_t evc_griffin_lim_workspace_bytes(int T, int fft_size, int hop, int iters);
 int evc_griffin_lim(const void* mag, int ldm, int T, int fft_size, int hop, int iters, void* x,
                     void* workspace, size_t workspace_bytes, double* rmse_out, evc_stream_t stream);
+
+/* Dynamic-time-warping alignment of parallel utterance pairs - the step that builds the parallel
+ * dictionary: _dtw_alignment(), 01_make_dict_parallel.py:215-228, i.e. the third-party call
+ * dtw(feat_A.T, feat_B.T, dist=lambda x, y: sum(np.square(x - y))) (accumulated cost with steps
+ * (i-1,j-1), (i-1,j), (i,j-1); trace-back with ties to the diagonal, then to i-1).  float64.
+ *   A, B      : frames as rows (row strides lda, ldb), D features each; pair p owns rows
+ *               a_offsets[p] .. a_offsets[p+1]-1 of A and b_offsets[p] .. of B (host arrays, n_pairs+1)
+ *   path_a/b  : device int arrays of sum_p (Ta_p + Tb_p) entries; pair p's path starts at
+ *               a_offsets[p] + b_offsets[p] and has path_len[p] (device, n_pairs) entries
+ *   total     : device, n_pairs doubles or NULL: accumulated cost of the last cell
+ * Frames per utterance are limited by the LDS wavefront buffers (about 6800). */
+size_t evc_dtw_workspace_bytes(const int* a_offsets, const int* b_offsets, int n_pairs);
+int evc_dtw_align(const void* A, int lda, const int* a_offsets, const void* B, int ldb,
+                  const int* b_offsets, int D, int n_pairs, int* path_a, int* path_b, int* path_len,
+                  double* total, void* workspace, size_t workspace_bytes, evc_stream_t stream);
 
 #ifdef __cplusplus
 }
