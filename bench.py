@@ -90,6 +90,29 @@ def cpu_baseline(M, N, K, seed, budget_frames):
     o.pymf_factorize(p["X"][:, :Tq], p["A"], H0, niter=K, compute_err=False)
     dtl = time.perf_counter() - t0
     out["pymf_literal_frames_per_s"] = Tq / dtl
+    # the installed scikit-learn itself (what 04_align_n_nmf.py:212 calls), same sample, all threads
+    try:
+        import warnings
+        from sklearn.decomposition import non_negative_factorization
+        t0 = time.perf_counter()
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            non_negative_factorization(X=X_rows, H=W_rows, init="custom", update_H=False, n_components=N,
+                                       beta_loss="frobenius", solver="mu", tol=0, max_iter=K)
+        out["sklearn_installed_frames_per_s"] = T / (time.perf_counter() - t0)
+    except Exception as e:  # noqa: BLE001
+        out["sklearn_installed_frames_per_s"] = None
+        out["sklearn_note"] = repr(e)[:120]
+    # one BLAS thread, an eighth of the utterance
+    try:
+        import threadpoolctl
+        T8 = max(16, T // 8)
+        with threadpoolctl.threadpool_limits(limits=1):
+            t0 = time.perf_counter()
+            o.sklearn_mu_fixed_dictionary(X_rows[:T8], W_rows, max_iter=K, tol=0.0)
+            out["single_thread_frames_per_s"] = T8 / (time.perf_counter() - t0)
+    except Exception:
+        pass
     return out, (p, act, Y)
 
 

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""The script's DEFAULT call semantics (`_factorize`: tol=1e-4, stop test every 10 iterations, <=150) on a batch
+of utterances - per-utterance stop rules evaluated on the device between 10-iteration launches."""
+import json, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import exemplars_vc_amd as evc
+
+U, Tu, M, N = 96, 688, 25, 4096
+dev = torch.device("cuda")
+g = torch.Generator(device=dev); g.manual_seed(3)
+A = torch.rand(N, M, generator=g, device=dev, dtype=torch.float64) + 1e-3
+A /= A.norm(dim=1, keepdim=True)
+Hs = torch.rand(U * Tu, N, generator=g, device=dev, dtype=torch.float64)
+Hs *= (torch.rand(U * Tu, N, generator=g, device=dev, dtype=torch.float64) < 8.0 / N)
+X = (Hs @ A + 1e-6).contiguous(); del Hs
+offs = np.arange(U + 1, dtype=np.int32) * Tu
+H = torch.empty(U * Tu, N, dtype=torch.float64, device=dev)
+for tol, iters in [(0.0, 150), (1e-4, 150), (1e-3, 150)]:
+    for rep in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        _, info = evc.solve_activations(A, X, layout="frame_major", iters=iters, eps_mode="zero_replace", init="sklearn",
+                                        utt_offsets=offs, out=H, check_every=10 if tol > 0 else 0,
+                                        stop_rule="sklearn" if tol > 0 else "none", tol=tol, info=True)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    ni = info["n_iter"]
+    print(json.dumps({"tol": tol, "max_iter": iters, "seconds": dt, "frames_per_s": U * Tu / dt,
+                      "n_iter_min": int(ni.min()), "n_iter_max": int(ni.max()), "n_iter_mean": float(ni.mean()),
+                      "frame_iterations_per_s": float(ni.mean()) * U * Tu / dt}))
