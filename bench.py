@@ -62,6 +62,7 @@ def cpu_baseline(M, N, K, seed, budget_frames):
     X_rows = np.ascontiguousarray(p["X"].T)
     W_rows = np.ascontiguousarray(p["A"].T)
     B_rows = np.ascontiguousarray(p["B"].T)
+    o.sklearn_mu_fixed_dictionary(X_rows[:32], W_rows, max_iter=2, tol=0.0)     # BLAS thread pool warm-up
     t0 = time.perf_counter()
     act, n_iter, _ = o.sklearn_mu_fixed_dictionary(X_rows, W_rows, max_iter=K, tol=0.0)
     Y = o.s4_convert(act.T, B_rows)
