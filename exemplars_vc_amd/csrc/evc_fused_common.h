@@ -55,9 +55,12 @@ struct FusedArgs {
 //   * one unsigned range test per tile (high words, v_max3) decides between the fast path and the
 //     exact path.  Fast path = every denominator is a normal number in [lo, 2^928): then neither
 //     the ==0 replacement nor the clamp can fire, and the quotient is formed as
-//     r = v_rcp_f64(den) (~23 bits), one Newton step (~46 bits), q = num*r, one residual
-//     correction (error ~ (2^-46)^2 -> correctly rounded to ~1 ulp): 7 VALU per element, no
-//     v_div_scale/fmas/fixup and no selects;
+//     r = v_rcp_f64(den) (2^-24.4), one Newton step (2^-48.8 = 2.3e-15 relative, measured by
+//     tools/ubench/rcp_accuracy.hip), q = num*r: 5 VALU per element, no v_div_scale/fmas/fixup and
+//     no selects.  The 10-ulp quotient is the same size as the rounding noise of the N-term
+//     denominator sums next to it; a residual correction would make the quotient correctly
+//     rounded for 2 more VALU per element (2.7 % of the kernel) and moves the end-to-end
+//     difference to the oracle by less than its spread - not taken;
 //   * the exact path (zero / denormal / huge / NaN denominators, and the unguarded NONE mode
 //     always) applies the guard literally and divides with IEEE semantics, so inf/NaN behaviour
 //     is the reference's.
@@ -65,9 +68,7 @@ __device__ __forceinline__ double fast_div(double num, double den) {
     double r = __builtin_amdgcn_rcp(den);
     const double e = __builtin_fma(-den, r, 1.0);
     r = __builtin_fma(r, e, r);
-    const double qv = num * r;
-    const double rem = __builtin_fma(-den, qv, num);
-    return __builtin_fma(rem, r, qv);
+    return num * r;
 }
 __device__ __forceinline__ unsigned hi_word(double x) { return (unsigned)(__double_as_longlong(x) >> 32); }
 // lowest admissible high word for the fast path: 2^-928, or one binade above eps when clamping
@@ -81,8 +82,8 @@ __device__ __forceinline__ unsigned fast_lo(int mode, double eps) {
 }
 // MUL_FIRST: pymf / nmf_tool form (h*p)/den, else sklearn / deComP form h*(p/den).  `mode` is only
 // consulted on the exact path.
-template <bool MUL_FIRST>
-__device__ __forceinline__ void mu_tile(double (&h)[4], const f64x4& p, const f64x4& dacc, int mode,
+template <bool MUL_FIRST, class HT>
+__device__ __forceinline__ void mu_tile(HT& h, const f64x4& p, const f64x4& dacc, int mode,
                                         double eps, unsigned lo) {
     const unsigned span = 0x79F00000u - lo;
     const unsigned worst = max(max(hi_word(dacc[0]) - lo, hi_word(dacc[1]) - lo),

@@ -35,6 +35,15 @@ namespace evc {
 
 constexpr int RNW = 8;    // wavefronts per workgroup
 
+// One tile's four activations of a lane.  The elements sit 16 bytes apart on purpose: stored back to
+// back, the optimiser merges their stores into vector stores and promotes the array to one 8-register
+// tuple, and a tuple crosses the update's rare-path merge as a unit (register copies on the fast path).
+struct HTile {
+    double v[4][2];
+    __device__ __forceinline__ double& operator[](int r) { return v[r][0]; }
+    __device__ __forceinline__ const double& operator[](int r) const { return v[r][0]; }
+};
+
 // KL: the generalised Kullback-Leibler update (A1p holds the dictionary divided by its column sums; the
 // per-unit work is one MFMA chain (A_j/colsum)^T (X / max(V, eps)) and a multiply, no division).
 template <int MSTEPS, int RES, int PL, bool KL>
@@ -93,9 +102,15 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
         const f64x2* t = reinterpret_cast<const f64x2*>(A1p + (a1w + sw + (long)k * (RNW * MSP * 64)));
 #pragma unroll
         for (int s = 0; s < MSTEPS; s += 2) {
-            const f64x2 v = t[(s >> 1) * 64 + ul];
-            a1[s] = v[0];
-            if (s + 1 < MSTEPS) a1[s + 1] = v[1];
+            if (s + 1 < MSTEPS) {
+                const f64x2 v = t[(s >> 1) * 64 + ul];
+                a1[s] = v[0];
+                a1[s + 1] = v[1];
+            } else {
+                // odd tail: load 8 bytes only - a 16-byte load would leave a dead register pair that the
+                // allocator reuses while the load is still in flight (write-after-write => vmcnt(0))
+                a1[s] = reinterpret_cast<const double*>(&t[(s >> 1) * 64 + ul])[0];
+            }
         }
     };
     auto load_a2 = [&](double (&a2)[MT][4], int k) {
@@ -109,7 +124,7 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
                 a2[u][r + 1] = v[1];
             }
     };
-    auto load_h = [&](double (&h)[4], int k) {
+    auto load_h = [&](HTile& h, int k) {
         const f64x2* t = Hp + (hw + sw + (long)k * (RNW * 128));
 #ifdef EVC_RES_NT
         const f64x2 h01 = __builtin_nontemporal_load(&t[ul]), h23 = __builtin_nontemporal_load(&t[ul + 64]);
@@ -118,7 +133,7 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
 #endif
         h[0] = h01[0]; h[1] = h01[1]; h[2] = h23[0]; h[3] = h23[1];
     };
-    auto store_h = [&](const double (&h)[4], int k) {
+    auto store_h = [&](const HTile& h, int k) {
         f64x2* t = Hp + (hw + sw + (long)k * (RNW * 128));
 #ifdef EVC_RES_NT
         __builtin_nontemporal_store(f64x2{h[0], h[1]}, &t[ul]);
@@ -128,7 +143,7 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
         t[ul + 64] = f64x2{h[2], h[3]};
 #endif
     };
-    auto vacc = [&](const double (&a2)[MT][4], const double (&h)[4], f64x4 (&vn)[MT]) {
+    auto vacc = [&](const double (&a2)[MT][4], const HTile& h, f64x4 (&vn)[MT]) {
 #pragma unroll
         for (int u = 0; u < MT; ++u)
 #pragma unroll
@@ -166,7 +181,7 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
             }
         }
     };
-    auto unit = [&](double (&a1)[MSTEPS], double (&a2)[MT][4], double (&h)[4], f64x4 (&vn)[MT], int k,
+    auto unit = [&](double (&a1)[MSTEPS], double (&a2)[MT][4], HTile& h, f64x4 (&vn)[MT], int k,
                     bool more) {
         __builtin_amdgcn_sched_barrier(0);       // keep the unrolled units' loads where they are written
         load_a2(a2, k);
@@ -178,12 +193,16 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
         else mu_tile<false>(h, p, d, mode, eps, lo);
     };
 
-    double hres[RES][4];
+    HTile hres[RES];
 #pragma unroll
     for (int k = 0; k < RES; ++k) load_h(hres[k], 2 * k);
 
     double a1[MSTEPS], a2[MT][4];
-    double hs[2][4];
+    // The two streamed-tile buffers are separate arrays on purpose: as one `hs[2][4]` they are
+    // promoted to a single 16-register tuple, and the update of one half then copies - and waits
+    // for - the other half, which has its prefetch in flight.
+    static_assert(RES % 2 == 0, "the streamed buffers alternate in pairs of units");
+    HTile hsa, hsb;
     for (it = 0; it < a.iters; ++it) {
         // opaque to the optimiser: the per-tile addresses are re-derived with scalar adds in every
         // sweep instead of being hoisted out of this loop into ~200 SGPRs (which then spill)
@@ -193,14 +212,12 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
         for (int u = 0; u < MT; ++u) vn[u] = f64x4{0, 0, 0, 0};
         if (it == 0) {
             load_a1(a1, 0);
-            load_h(hs[0], 1);
+            load_h(hsa, 1);
         }
-#pragma unroll
-        for (int k2 = 0; k2 < RES; ++k2) {
-            // even tile 2*k2: resident
+        // resident tile 2*k2, then streamed tile 2*k2+1 held in `cur`; `nxt` receives tile 2*k2+3
+        auto pair = [&](int k2, HTile& cur, HTile& nxt) {
             unit(a1, a2, hres[k2], vn, 2 * k2, true);
             vacc(a2, hres[k2], vn);
-            // odd tile 2*k2+1: streamed; its successor's load goes out now, two units ahead of its use
             const bool more = (2 * k2 + 2 < KT);
             __builtin_amdgcn_sched_barrier(0);
             load_a2(a2, 2 * k2 + 1);
@@ -209,17 +226,22 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
                 dp(a1, d, p, 2 * k2 + 1);
                 if (more) load_a1(a1, 2 * k2 + 2);
                 __builtin_amdgcn_sched_barrier(0);
-                if (KL) { for (int r = 0; r < 4; ++r) hs[k2 & 1][r] *= p[r]; }
-                else mu_tile<false>(hs[k2 & 1], p, d, mode, eps, lo);
+                if (KL) { for (int r = 0; r < 4; ++r) cur[r] *= p[r]; }
+                else mu_tile<false>(cur, p, d, mode, eps, lo);
             }
             // the next streamed tile's load goes out here, two units ahead of its use (after the update:
             // registers with a load in flight must not cross the update's rare-path merge)
-            if (k2 + 1 < RES) load_h(hs[(k2 + 1) & 1], 2 * k2 + 3);
-            store_h(hs[k2 & 1], 2 * k2 + 1);
-            vacc(a2, hs[k2 & 1], vn);
+            if (k2 + 1 < RES) load_h(nxt, 2 * k2 + 3);
+            store_h(cur, 2 * k2 + 1);
+            vacc(a2, cur, vn);
+        };
+#pragma unroll
+        for (int k2 = 0; k2 < RES; k2 += 2) {
+            pair(k2, hsa, hsb);
+            pair(k2 + 1, hsb, hsa);
         }
         for (int k = 2 * RES; k < KT; ++k) {     // beyond the resident window: plain streaming
-            double h[4];
+            HTile h;
             load_h(h, k);
             unit(a1, a2, h, vn, k, k + 1 < KT);
             store_h(h, k);
@@ -228,7 +250,7 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
         // the next sweep's first operands do not depend on V': request them before the combine
         if (it + 1 < a.iters) {
             load_a1(a1, 0);
-            load_h(hs[0], 1);      // tile 1 was stored earlier in this sweep by this very wavefront
+            load_h(hsa, 1);        // tile 1 was stored earlier in this sweep by this very wavefront
         }
         // V' partials -> LDS -> each wavefront sums a slice over the partials in fixed order -> vL
 #pragma unroll
