@@ -5,8 +5,9 @@ A "step" is one pass of the hot path over one batch of synthetic utterances alre
 resident in HBM: activation solve (K multiplicative updates against the fixed dictionary A,
 scikit-learn semantics as called by 04_align_n_nmf.py: constant init, zero->EPSILON guard,
 fixed K, no early stop) followed by the synthesis Y = B H.  Default workload is BASELINE.json
-configs[1] ("C2"): M=25 bins, N=4096 exemplars, K=100, float64, 192 utterances x 688 frames
-(the size of the reference's corpus: 162 utterances, BASELINE.md C4, rounded up).
+configs[1] ("C2"): M=25 bins, N=4096 exemplars, K=100, float64, 256 utterances x 688 frames
+(the reference's corpus is 162 utterances; 256 is the next count whose
+256 x 43 sixteen-frame workgroups fill the 256 CUs in whole rounds).
 
   python bench.py [--gpus N --steps K --warmup W]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -125,7 +126,7 @@ def main():
     ap.add_argument("--bins", type=int, default=25)
     ap.add_argument("--exemplars", type=int, default=4096)
     ap.add_argument("--iters", type=int, default=100)
-    ap.add_argument("--utterances", type=int, default=192)
+    ap.add_argument("--utterances", type=int, default=256)
     ap.add_argument("--frames", type=int, default=688, help="frames per utterance")
     ap.add_argument("--algo", default="factored", choices=["factored", "gram", "literal"])
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])

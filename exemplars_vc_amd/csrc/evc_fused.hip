@@ -309,9 +309,10 @@ __global__ __launch_bounds__(NW * 64) void k_fused_mu(FusedArgs a) {
                             p = Mma<double>::mma(R.a1[s], xL[(c * MT * 4 + s) * 64 + lane], p);
                         }
                     }
-                    double h[4] = {R.h01[c][0], R.h01[c][1], R.h23[c][0], R.h23[c][1]};
+                    HTile h;
+                    h[0] = R.h01[c][0]; h[1] = R.h01[c][1]; h[2] = R.h23[c][0]; h[3] = R.h23[c][1];
                     if (MASKED) {
-                        double hn[4] = {h[0], h[1], h[2], h[3]};
+                        HTile hn = h;
                         if (KL) { for (int r = 0; r < 4; ++r) hn[r] *= p[r]; }
                         else mu_tile<MUL_FIRST>(hn, p, d, mode, eps, lo);
                         const int n0 = 16 * j + 4 * q;

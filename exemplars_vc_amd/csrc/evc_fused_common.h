@@ -46,6 +46,15 @@ struct FusedArgs {
     double eps, l1;
 };
 
+// One tile's four activations of a lane.  The elements sit 16 bytes apart on purpose: stored back to
+// back, the optimiser merges their stores into vector stores and promotes the array to one 8-register
+// tuple, and a tuple crosses the update's rare-path merge as a unit (register copies on the fast path).
+struct HTile {
+    double v[4][2];
+    __device__ __forceinline__ double& operator[](int r) { return v[r][0]; }
+    __device__ __forceinline__ const double& operator[](int r) const { return v[r][0]; }
+};
+
 // The update with the guard mode as a compile-time constant (the switch is hoisted out of the
 // sweep).  On gfx950 an f64 MFMA and any VALU instruction of the same SIMD do not overlap
 // (tools/ubench/mfma_valu_f64.hip: times add), so the VALU instruction count of this function is

@@ -35,15 +35,6 @@ namespace evc {
 
 constexpr int RNW = 8;    // wavefronts per workgroup
 
-// One tile's four activations of a lane.  The elements sit 16 bytes apart on purpose: stored back to
-// back, the optimiser merges their stores into vector stores and promotes the array to one 8-register
-// tuple, and a tuple crosses the update's rare-path merge as a unit (register copies on the fast path).
-struct HTile {
-    double v[4][2];
-    __device__ __forceinline__ double& operator[](int r) { return v[r][0]; }
-    __device__ __forceinline__ const double& operator[](int r) const { return v[r][0]; }
-};
-
 // KL: the generalised Kullback-Leibler update (A1p holds the dictionary divided by its column sums; the
 // per-unit work is one MFMA chain (A_j/colsum)^T (X / max(V, eps)) and a multiply, no division).
 template <int MSTEPS, int RES, int PL, bool KL>
