@@ -10,6 +10,7 @@ Argument meaning, return orientation, errors and warnings follow the reference c
 """
 from __future__ import annotations
 
+import os
 import warnings
 
 import numpy as np
@@ -109,7 +110,8 @@ def _stack(feats, key, transform=None):
     return np.concatenate(rows, axis=0)
 
 
-def factorize(tobe_converted, src_feat, *, use_stft=True, tol=1e-4, device=None):
+def factorize(tobe_converted, src_feat, *, use_stft=True, tol=1e-4, device=None, cache_dir=None,
+              cache_key="content"):
     """`factorize(tobe_converted, src_feat)` of 04_align_n_nmf.py:218-333: stack the aligned source
     exemplars into the dictionary, solve the activations of the utterance to convert (one solve per
     feature stream), and - WORLD branch - form the reference's residual.
@@ -118,22 +120,54 @@ def factorize(tobe_converted, src_feat, *, use_stft=True, tol=1e-4, device=None)
       use_stft=True : tobe_converted['real'] (T x 201), src_feat[i]['real'] -> ({'H_stft': N x T}, None)
       use_stft=False: 'sp', 'ap' (T x 513) and 'f0' (T,) -> ({'H_sp','H_ap','H_f0'}, {'r_sp','r_ap','r_f0'})
     The residual is the reference's literal expression np.log(H.T @ A - conv) (:292-294), which is NaN
-    wherever the reconstruction undershoots; it is reproduced, not repaired.  The reference's pickle
-    cache (keyed by the NUMBER of dictionary files only, so it returns a stale H for a different
-    utterance) is deliberately not reproduced.
+    wherever the reconstruction undershoots; it is reproduced, not repaired.
+
+    cache_dir (the reference hard-codes its working directory; None = no files): the activation /
+    residual pickles of :251-260,296-308,330-331 are read when present and written after a solve
+    (compat.artifacts).  The reference names them by the NUMBER of dictionary files only, so a second
+    utterance gets the first one's H back; cache_key="content" (default) adds a digest of the
+    utterance and the dictionary to the name, cache_key="reference" reproduces the reference's name
+    (and its hazard) so that caches written by the reference are found.
     """
+    from . import artifacts
     if use_stft:
         conv_stft = np.abs(np.asarray(tobe_converted["real"]))
         A_stft = _stack(src_feat, "real", np.abs)
-        return {"H_stft": _factorize(conv_stft, A_stft, tol=tol, device=device)}, None
+        hpath = None
+        if cache_dir is not None:
+            dg = artifacts.content_digest(conv_stft, A_stft) if cache_key == "content" else None
+            hpath = artifacts.activation_cache_path(cache_dir, True, len(src_feat), "H", cache_key, dg)
+            if os.path.isfile(hpath):
+                return artifacts.read_activations(hpath, True), None
+        H = {"H_stft": _factorize(conv_stft, A_stft, tol=tol, device=device)}
+        if hpath is not None:
+            artifacts.write_activations(hpath, H)
+        return H, None
     streams = {"sp": (np.asarray(tobe_converted["sp"]), _stack(src_feat, "sp")),
                "ap": (np.asarray(tobe_converted["ap"]), _stack(src_feat, "ap")),
                "f0": (np.asarray(tobe_converted["f0"])[:, np.newaxis], _stack(src_feat, "f0"))}
+    hpath = rpath = None
     H, R = {}, {}
+    if cache_dir is not None:
+        dg = (artifacts.content_digest(*[a for pair in streams.values() for a in pair])
+              if cache_key == "content" else None)
+        hpath = artifacts.activation_cache_path(cache_dir, False, len(src_feat), "H", cache_key, dg)
+        rpath = artifacts.activation_cache_path(cache_dir, False, len(src_feat), "R", cache_key, dg)
+        if os.path.isfile(hpath):
+            H = artifacts.read_activations(hpath, False)
+            if os.path.isfile(rpath):
+                return H, artifacts.read_residuals(rpath)
     for name, (conv, A) in streams.items():
-        H["H_" + name] = _factorize(conv, A, tol=tol, device=device)
+        if "H_" + name not in H:
+            H["H_" + name] = _factorize(conv, A, tol=tol, device=device)
+        # a cached H without its R: the residual is recomputed from it (:261-276; the expression there,
+        # np.matmul(A, H), has its operands the wrong way round and cannot run - :292-294's is used)
         with np.errstate(invalid="ignore", divide="ignore"):
             R["r_" + name] = np.log(synthesize_rows(H["H_" + name], A, device=device) - conv)
+    if hpath is not None:
+        if not os.path.isfile(hpath):
+            artifacts.write_activations(hpath, H)
+        artifacts.write_residuals(rpath, R)
     return H, R
 
 
