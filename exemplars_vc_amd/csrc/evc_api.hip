@@ -516,6 +516,29 @@ int evc_griffin_lim(const void* mag, int ldm, int T, int fft_size, int hop, int 
                        workspace, rmse_out, reinterpret_cast<hipStream_t>(stream));
 }
 
+int evc_stft_frames(long n_samples, int fft_size, int hop, int center) {
+    if (n_samples < 1 || fft_size < 2 || (fft_size & 1) || hop < 1) return 0;
+    return stft_frames(n_samples, hop, center != 0, fft_size);
+}
+
+size_t evc_stft_workspace_bytes(long n_samples, int fft_size, int hop, int center) {
+    if (n_samples < 1 || fft_size < 2 || (fft_size & 1) || hop < 1) return 0;
+    return stft_workspace_bytes(n_samples, fft_size, hop, center != 0);
+}
+
+int evc_stft(const void* x, long n_samples, int fft_size, int hop, int center, void* re, int ldre, void* im,
+             int ldim, void* workspace, size_t workspace_bytes, evc_stream_t stream) {
+    if (n_samples < 0 || fft_size < 2 || (fft_size & 1) || hop < 1) return ST_BADARG;
+    if (n_samples > (1L << 31) - 4096) return ST_BADARG;        // frame counts are ints
+    if (n_samples == 0 || stft_frames(n_samples, hop, center != 0, fft_size) == 0) return ST_OK;
+    const int nb = fft_size / 2 + 1;
+    if (!x || !re || !im || !workspace || ldre < nb || ldim < nb) return ST_BADARG;
+    if (workspace_bytes < stft_workspace_bytes(n_samples, fft_size, hop, center != 0)) return ST_WORKSPACE;
+    return (int)stft_run(static_cast<const double*>(x), n_samples, fft_size, hop, center != 0,
+                         static_cast<double*>(re), ldre, static_cast<double*>(im), ldim, workspace,
+                         reinterpret_cast<hipStream_t>(stream));
+}
+
 static bool dtw_offsets_ok(const int* off, int n_pairs) {
     if (!off || off[0] != 0) return false;
     for (int p = 0; p < n_pairs; ++p)

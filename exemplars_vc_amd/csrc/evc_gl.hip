@@ -34,13 +34,15 @@ static GlDims gl_dims(int T_, int F, int hop) {
     return d;
 }
 
-// np.hanning(F)[n]
-__device__ __forceinline__ double hanning(int n, int F) {
-    return F < 2 ? 1.0 : 0.5 - 0.5 * cospi(2.0 * n / (double)(F - 1));
+// np.hanning(F)[n] (symmetric: period F-1, zz_audio_utilities.py:196,212) or, periodic, scipy's
+// get_window('hann', F) = the window librosa.stft applies (period F)
+__device__ __forceinline__ double hanning(int n, int F, bool periodic = false) {
+    return F < 2 ? 1.0 : 0.5 - 0.5 * cospi(2.0 * n / (double)(periodic ? F : F - 1));
 }
 
 // W_f[j][n] (J1 x K1) and W_i[n][k] (J2 x K2), zero in the padding
-__global__ __launch_bounds__(256) void k_gl_tables(GlDims d, double* __restrict__ Wf, double* __restrict__ Wi) {
+__global__ __launch_bounds__(256) void k_gl_tables(GlDims d, double* __restrict__ Wf, double* __restrict__ Wi,
+                                                   bool periodic) {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     const long n1 = (long)d.J1 * d.K1, n2 = (long)d.J2 * d.K2;
     if (gid < n1) {
@@ -49,10 +51,10 @@ __global__ __launch_bounds__(256) void k_gl_tables(GlDims d, double* __restrict_
         if (n < d.F && j < 2 * d.nb) {
             const int k = j < d.nb ? j : j - d.nb;
             const double ang = 2.0 * (double)(((long)k * n) % d.F) / (double)d.F;   // exact argument reduction
-            v = hanning(n, d.F) * (j < d.nb ? cospi(ang) : -sinpi(ang));
+            v = hanning(n, d.F, periodic) * (j < d.nb ? cospi(ang) : -sinpi(ang));
         }
         Wf[gid] = v;
-    } else if (gid < n1 + n2) {
+    } else if (Wi && gid < n1 + n2) {
         const long g = gid - n1;
         const int n = (int)(g / d.K2), kk = (int)(g % d.K2);
         double v = 0.0;
@@ -145,7 +147,7 @@ hipError_t gl_run(const double* mag, long ldm, int T_, int F, int hop, int iters
     double* tr = take((size_t)(iters > 0 ? iters : 1));
 
     const long nt = (long)d.J1 * d.K1 + (long)d.J2 * d.K2;
-    hipLaunchKernelGGL(k_gl_tables, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, d, Wf, Wi);
+    hipLaunchKernelGGL(k_gl_tables, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, d, Wf, Wi, false);
     hipLaunchKernelGGL(k_gl_load_x, dim3((unsigned)((d.Lp + 255) / 256)), dim3(256), 0, s, x, d.L, d.Lp, xa);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -171,6 +173,83 @@ hipError_t gl_run(const double* mag, long ldm, int T_, int F, int hop, int iters
         e = hipStreamSynchronize(s);
         if (e != hipSuccess) return e;
     }
+    return hipGetLastError();
+}
+
+// ---- STFT front end: librosa.core.stft(y, n_fft, hop_length, window='hann') as called at
+// 04_align_n_nmf.py:422 and 03_a_b_r_parallel.py:103 - centred frames over the reflect-padded signal,
+// periodic Hann window, rfft.  Same contraction as the Griffin-Lim analysis step: S = frames(xp) W_f.
+
+// xp[i] = x[reflect(i - pad)] (numpy 'reflect': the edge sample is not repeated), zero beyond the padded
+// signal (the padded GEMM rows read it)
+__global__ __launch_bounds__(256) void k_stft_pad(const double* __restrict__ x, long L, int pad, long Lp,
+                                                  double* __restrict__ xp) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Lp) return;
+    double v = 0.0;
+    if (i < L + 2L * pad) {
+        long s = i - pad;
+        if (L == 1) s = 0;
+        else {
+            const long period = 2 * (L - 1);
+            s %= period;
+            if (s < 0) s += period;
+            if (s >= L) s = period - s;
+        }
+        v = x[s];
+    }
+    xp[i] = v;
+}
+
+__global__ __launch_bounds__(256) void k_stft_split(const double* __restrict__ S, int lds_, int T_, int nb,
+                                                    double* __restrict__ re, long ldre, double* __restrict__ im,
+                                                    long ldim) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long)T_ * nb) return;
+    const long t = gid / nb;
+    const int k = (int)(gid % nb);
+    re[t * ldre + k] = S[t * lds_ + k];
+    im[t * ldim + k] = S[t * lds_ + nb + k];
+}
+
+int stft_frames(long L, int hop, bool center, int F) {
+    if (center) return (int)(1 + L / hop);
+    return L < F ? 0 : (int)(1 + (L - F) / hop);
+}
+
+static GlDims stft_dims(long L, int F, int hop, bool center) {
+    GlDims d = gl_dims(stft_frames(L, hop, center, F) > 0 ? stft_frames(L, hop, center, F) : 1, F, hop);
+    const long need = L + (center ? 2L * (F / 2) : 0);
+    if (d.Lp < need) d.Lp = (need + 15) & ~15L;
+    return d;
+}
+
+size_t stft_workspace_bytes(long L, int F, int hop, bool center) {
+    const GlDims d = stft_dims(L, F, hop, center);
+    return ((size_t)d.J1 * d.K1 + (size_t)d.Tp * d.J1 + (size_t)d.Lp + 96) * sizeof(double) + 4 * 256;
+}
+
+hipError_t stft_run(const double* x, long L, int F, int hop, bool center, double* re, long ldre, double* im,
+                    long ldim, void* ws, hipStream_t s) {
+    const int T_ = stft_frames(L, hop, center, F);
+    if (T_ <= 0) return hipSuccess;
+    const GlDims d = stft_dims(L, F, hop, center);
+    double* p = static_cast<double*>(ws);
+    auto take = [&](size_t n) { double* q = p; p += (n + 31) & ~size_t(31); return q; };
+    double* Wf = take((size_t)d.J1 * d.K1);
+    double* S = take((size_t)d.Tp * d.J1);
+    double* xp = take((size_t)d.Lp);
+    const long nt = (long)d.J1 * d.K1;
+    hipLaunchKernelGGL(k_gl_tables, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, d, Wf, (double*)nullptr, true);
+    hipLaunchKernelGGL(k_stft_pad, dim3((unsigned)((d.Lp + 255) / 256)), dim3(256), 0, s, x, L, center ? F / 2 : 0,
+                       d.Lp, xp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = gemm_nt<double>(xp, hop, Wf, d.K1, S, d.J1, d.Tp, d.J1, d.K1, s);
+    if (e != hipSuccess) return e;
+    const long n = (long)T_ * d.nb;
+    hipLaunchKernelGGL(k_stft_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, S, d.J1, T_, d.nb, re, ldre,
+                       im, ldim);
     return hipGetLastError();
 }
 

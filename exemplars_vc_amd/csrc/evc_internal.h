@@ -164,6 +164,10 @@ hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttS
 
 // ----- evc_gl.hip -----
 size_t gl_workspace_bytes(int T_, int F, int hop, int iters);
+int stft_frames(long L, int hop, bool center, int F);
+size_t stft_workspace_bytes(long L, int F, int hop, bool center);
+hipError_t stft_run(const double* x, long L, int F, int hop, bool center, double* re, long ldre, double* im,
+                    long ldim, void* ws, hipStream_t s);
 hipError_t gl_run(const double* mag, long ldm, int T_, int F, int hop, int iters, double* x, void* ws,
                   double* rmse_host, hipStream_t s);
 

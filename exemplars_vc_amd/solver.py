@@ -325,6 +325,35 @@ def griffin_lim(magnitude_spectrogram, fft_size, hopsamp, iterations, x0, *, dev
     return (out, rmse[:iterations]) if want_rmse else out
 
 
+def stft(y, n_fft=400, hop_length=80, *, center=True, device=None):
+    """STFT front end on the GPU (float64): samples y -> (re, im), each (n_frames, n_fft/2+1) with rows
+    as time slices - the transposed layout the scripts store (`lbr.core.stft(...).T`,
+    04_align_n_nmf.py:422-427).  Periodic Hann window, reflect-padded centred frames (librosa's
+    defaults)."""
+    torch = _torch()
+    device = require_device(device)
+    L = _lib.lib()
+    was_np = not isinstance(y, torch.Tensor)
+    x = torch.as_tensor(np.asarray(y, dtype=np.float64) if was_np else y, dtype=torch.float64).to(device).contiguous()
+    if x.dim() != 1:
+        raise ValueError("y must be one-dimensional")
+    n, n_fft, hop_length = int(x.numel()), int(n_fft), int(hop_length)
+    if n_fft < 2 or n_fft % 2 or hop_length < 1:
+        raise ValueError("n_fft must be even and >= 2, hop_length >= 1")
+    nb = n_fft // 2 + 1
+    T = int(L.evc_stft_frames(n, n_fft, hop_length, int(center))) if n else 0
+    re = torch.empty(T, nb, dtype=torch.float64, device=device)
+    im = torch.empty(T, nb, dtype=torch.float64, device=device)
+    if T:
+        ws = _workspace(int(L.evc_stft_workspace_bytes(n, n_fft, hop_length, int(center))), device)
+        with torch.cuda.device(device):
+            stream = torch.cuda.current_stream(device).cuda_stream
+            st = L.evc_stft(x.data_ptr(), n, n_fft, hop_length, int(center), re.data_ptr(), nb, im.data_ptr(), nb,
+                            ws.data_ptr(), ws.numel(), C.c_void_p(stream))
+        _lib.check(st, "evc_stft")
+    return (re.cpu().numpy(), im.cpu().numpy()) if was_np else (re, im)
+
+
 def dtw_align(feats_a, feats_b, *, device=None, want_cost=False):
     """DTW paths of parallel utterance pairs on the GPU.  feats_a[p], feats_b[p]: (frames, features)
     float64 arrays of pair p.  Returns a list of (path_a, path_b) int arrays [, accumulated costs]:

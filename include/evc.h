@@ -14,6 +14,7 @@
  *   evc_synthesize  replaces np.matmul(H.T, B) in convert()  04_align_n_nmf.py:371-373,391
  *   evc_nmf_convert both of the above back to back (factorize() + convert(), :452-455)
  *   evc_griffin_lim replaces reconstruct_signal_griffin_lim()  zz_audio_utilities.py:258-292
+ *   evc_stft        replaces librosa.core.stft(...) of 04_align_n_nmf.py:422
  *   evc_dtw_align   replaces _dtw_alignment() / dtw_alignment()  01_make_dict_parallel.py:215-249
  *   evc_residual    replaces sklearn _beta_divergence(beta=2, square_root=True)
  *                   (_nmf.py:85-135) and pymf frobenius_norm (pymf/base.py:144-165)
@@ -171,6 +172,19 @@ int evc_residual(const void* A, int lda, const void* X, int ldx, const void* H, 
                  int M, int N, int T, int layout, int dtype,
                  double* err2_out, void* workspace, size_t workspace_bytes,
                  evc_stream_t stream);
+
+/* STFT front end - the feature extraction that feeds the path when the scripts run on STFT features:
+ * librosa.core.stft(y, n_fft=400, hop_length=80, window='hann') at 04_align_n_nmf.py:422 and
+ * 03_a_b_r_parallel.py:103 (librosa is a third-party dependency absent here; its published algorithm
+ * is restated: frames centred by reflect-padding n_fft/2 samples, periodic Hann window, rfft).  float64.
+ *   x      : n_samples doubles (device)
+ *   re, im : n_frames x (fft_size/2 + 1), rows are time slices (device) - i.e. the transposed `.T`
+ *            the scripts store; n_frames = evc_stft_frames(n_samples, fft_size, hop, center)
+ *   center : 1 = librosa's default (reflect padding), 0 = frames start at sample 0            */
+int evc_stft_frames(long n_samples, int fft_size, int hop, int center);
+size_t evc_stft_workspace_bytes(long n_samples, int fft_size, int hop, int center);
+int evc_stft(const void* x, long n_samples, int fft_size, int hop, int center, void* re, int ldre,
+             void* im, int ldim, void* workspace, size_t workspace_bytes, evc_stream_t stream);
 
 /* Griffin-Lim phase reconstruction - the back end that follows the path when the scripts run on
  * STFT magnitudes: reconstruct_signal_griffin_lim(), zz_audio_utilities.py:258-292 (with its
