@@ -110,8 +110,11 @@ def _stack(feats, key, transform=None):
     return np.concatenate(rows, axis=0)
 
 
+RESIDUAL_FLOOR = 1e-10   # positive floor of the log-ratio residual (not in the reference)
+
+
 def factorize(tobe_converted, src_feat, *, use_stft=True, tol=1e-4, device=None, cache_dir=None,
-              cache_key="content"):
+              cache_key="content", residual="reference"):
     """`factorize(tobe_converted, src_feat)` of 04_align_n_nmf.py:218-333: stack the aligned source
     exemplars into the dictionary, solve the activations of the utterance to convert (one solve per
     feature stream), and - WORLD branch - form the reference's residual.
@@ -121,6 +124,9 @@ def factorize(tobe_converted, src_feat, *, use_stft=True, tol=1e-4, device=None,
       use_stft=False: 'sp', 'ap' (T x 513) and 'f0' (T,) -> ({'H_sp','H_ap','H_f0'}, {'r_sp','r_ap','r_f0'})
     The residual is the reference's literal expression np.log(H.T @ A - conv) (:292-294), which is NaN
     wherever the reconstruction undershoots; it is reproduced, not repaired.
+    residual="log_ratio" (an extension, SURVEY 8f-4: what the script's comment `log r_n = log y_n -
+    log y_hat_n` (:263) describes) stores r = log max(y, floor) - log max(H.T @ A, floor) instead; pass the
+    same value to convert().
 
     cache_dir (the reference hard-codes its working directory; None = no files): the activation /
     residual pickles of :251-260,296-308,330-331 are read when present and written after a solve
@@ -162,8 +168,14 @@ def factorize(tobe_converted, src_feat, *, use_stft=True, tol=1e-4, device=None,
             H["H_" + name] = _factorize(conv, A, tol=tol, device=device)
         # a cached H without its R: the residual is recomputed from it (:261-276; the expression there,
         # np.matmul(A, H), has its operands the wrong way round and cannot run - :292-294's is used)
-        with np.errstate(invalid="ignore", divide="ignore"):
-            R["r_" + name] = np.log(synthesize_rows(H["H_" + name], A, device=device) - conv)
+        recon = synthesize_rows(H["H_" + name], A, device=device)
+        if residual == "log_ratio":
+            R["r_" + name] = np.log(np.maximum(conv, RESIDUAL_FLOOR)) - np.log(np.maximum(recon, RESIDUAL_FLOOR))
+        elif residual == "reference":
+            with np.errstate(invalid="ignore", divide="ignore"):
+                R["r_" + name] = np.log(recon - conv)
+        else:
+            raise ValueError("residual must be 'reference' or 'log_ratio'")
     if hpath is not None:
         if not os.path.isfile(hpath):
             artifacts.write_activations(hpath, H)
@@ -171,15 +183,23 @@ def factorize(tobe_converted, src_feat, *, use_stft=True, tol=1e-4, device=None,
     return H, R
 
 
-def convert(H, tar_feat, residual=None, *, use_stft=True, device=None):
+def convert(H, tar_feat, residual=None, *, use_stft=True, device=None, residual_mode="reference"):
     """`convert(H, tar_feat, residual)` of 04_align_n_nmf.py:336-393: stack the parallel target
     exemplars and synthesise H.T @ B per stream; the WORLD branch applies the reference's residual
-    expression exp(log(H.T @ B) + log(r)) with NaNs of r zeroed first (:367-373), literally."""
+    expression exp(log(H.T @ B) + log(r)) with NaNs of r zeroed first (:367-373), literally;
+    residual_mode="log_ratio" applies the residual of factorize(residual="log_ratio"):
+    exp(log max(H.T @ B, floor) + r)."""
     if use_stft:
         return synthesize_rows(H["H_stft"], _stack(tar_feat, "real", np.abs), device=device)
     out = {}
     for name in ("sp", "ap", "f0"):
         B = _stack(tar_feat, name)
+        if residual_mode == "log_ratio":
+            y = np.maximum(synthesize_rows(H["H_" + name], B, device=device), RESIDUAL_FLOOR)
+            out[name] = np.exp(np.log(y) + np.asarray(residual["r_" + name]))
+            continue
+        if residual_mode != "reference":
+            raise ValueError("residual_mode must be 'reference' or 'log_ratio'")
         r = np.array(residual["r_" + name], copy=True)
         r[np.isnan(r)] = 0
         with np.errstate(invalid="ignore", divide="ignore"):

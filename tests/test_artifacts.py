@@ -159,3 +159,27 @@ def test_factorize_cache_semantics(tmp_path, monkeypatch, use_stft):
         _, Rr = fz.factorize(utt1, src, use_stft=False, cache_dir=root, cache_key="reference")
         assert len(calls) == n and set(Rr) == {"r_sp", "r_ap", "r_f0"}
         assert os.path.isfile(art.activation_cache_path(root, False, 2, "R"))
+
+
+def test_log_ratio_residual_extension(monkeypatch):
+    """factorize(residual='log_ratio') / convert(residual_mode='log_ratio') (not in the
+    reference): y_hat_target * y / y_hat_source on floored positives.  Host logic; the solve is the oracle."""
+    monkeypatch.setattr(fz, "_factorize", _oracle_factorize)
+    monkeypatch.setattr(fz, "synthesize_rows", lambda H, B, device=None: o.s4_convert(H, np.asarray(B)))
+    rng = np.random.default_rng(11)
+    src = [{"sp": rng.random((6, 9)) + 0.1, "ap": rng.random((6, 9)) + 0.1, "f0": rng.random(6) + 0.1} for _ in range(2)]
+    tar = [{"sp": rng.random((6, 9)) + 0.1, "ap": rng.random((6, 9)) + 0.1, "f0": rng.random(6) + 0.1} for _ in range(2)]
+    utt = {"sp": rng.random((4, 9)) + 0.05, "ap": rng.random((4, 9)) + 0.05, "f0": rng.random(4) + 0.05}
+    H, R = fz.factorize(utt, src, use_stft=False, residual="log_ratio")
+    assert all(np.isfinite(R[k]).all() for k in R)
+    out = fz.convert(H, tar, R, use_stft=False, residual_mode="log_ratio")
+    for name in ("sp", "ap"):
+        A = np.concatenate([f[name] for f in src]); B = np.concatenate([f[name] for f in tar])
+        want = (H["H_" + name].T @ B) * utt[name] / (H["H_" + name].T @ A)
+        np.testing.assert_allclose(out[name], want, rtol=1e-12)
+    assert out["f0"].shape == (4,)
+    # converting with the source's own exemplars returns the source exactly: the residual closes the gap
+    back = fz.convert(H, src, R, use_stft=False, residual_mode="log_ratio")
+    np.testing.assert_allclose(back["sp"], utt["sp"], rtol=1e-12)
+    with pytest.raises(ValueError):
+        fz.factorize(utt, src, use_stft=False, residual="nope")
