@@ -164,6 +164,10 @@ template <>
 int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_solve_opts& o, int n_utt,
                         hipStream_t s) {
     const int c_override = (o.reserved >> 8) & 0xff;     // 0 = automatic, 1 / 2 = general kernel
+    // pymf's stop rule compares successive errors against 2.2e-16: it only fires at the reference's
+    // iteration if the update reaches the same floating-point fixed point, i.e. with correctly rounded
+    // quotients (reserved bit 1 asks for them explicitly)
+    const int exact_div = (o.stop_rule == EVC_STOP_PYMF || (o.reserved & 2)) ? 1 : 0;
     if (o.loss == EVC_LOSS_KL) {     // D/P operand order from the scaled dictionary, V' operand order from A
         HIP_TRY(fused_pack_dict(w.fl, w.fb.A1p, nullptr, w.Akl, d.Mk, s));
         HIP_TRY(fused_pack_dict(w.fl, nullptr, w.fb.A2p, w.At, d.Mk, s));
@@ -174,7 +178,7 @@ int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_sol
     int first = 1;
     if (o.check_every > 0 && o.stop_rule == EVC_STOP_SKLEARN) {   // error_at_init
         HIP_TRY(fused_iterate(w.fl, w.fb, w.u, d.N, d.T_, 0, 1, 1, w.err2, o.eps_mode, o.eps, o.l1,
-                              c_override, 1, o.loss, s));
+                              c_override, 1, o.loss, exact_div, s));
         HIP_TRY(utt_check(w.err2, w.u, n_utt, 0, o.check_every, o.stop_rule, o.tol, s));
         first = 0;
     }
@@ -185,7 +189,7 @@ int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_sol
         bool check = false;
         if (o.check_every > 0 && n >= o.check_every) { n = o.check_every; check = true; }
         HIP_TRY(fused_iterate(w.fl, w.fb, w.u, d.N, d.T_, n, first, check ? 1 : 0, w.err2, o.eps_mode,
-                              o.eps, o.l1, c_override, o.stop_rule == EVC_STOP_NONE ? 1 : 0, o.loss, s));
+                              o.eps, o.l1, c_override, o.stop_rule == EVC_STOP_NONE ? 1 : 0, o.loss, exact_div, s));
         first = 0;
         done += n;
         if (check)

@@ -314,6 +314,7 @@ __global__ __launch_bounds__(NW * 64) void k_fused_mu(FusedArgs a) {
                     if (MASKED) {
                         HTile hn = h;
                         if (KL) { for (int r = 0; r < 4; ++r) hn[r] *= p[r]; }
+                        else if (a.exact_div) mu_tile<MUL_FIRST, true>(hn, p, d, mode, eps, lo);
                         else mu_tile<MUL_FIRST>(hn, p, d, mode, eps, lo);
                         const int n0 = 16 * j + 4 * q;
 #pragma unroll
@@ -324,6 +325,8 @@ __global__ __launch_bounds__(NW * 64) void k_fused_mu(FusedArgs a) {
                     } else if (KL) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) h[r] *= p[r];
+                    } else if (a.exact_div) {
+                        mu_tile<MUL_FIRST, true>(h, p, d, mode, eps, lo);
                     } else {
                         mu_tile<MUL_FIRST>(h, p, d, mode, eps, lo);
                     }
@@ -475,17 +478,18 @@ static hipError_t launch_general(const FusedLayout& f, const FusedArgs& a, int c
 // c_req: 0 = automatic (k_fused_res where it applies), 1 / 2 = force the general kernel with that many
 // frame tiles per workgroup (tests, A/B timing).
 // all_live_known: no stopping rule is in force, so every utterance is active for the whole call.
+// exact_div: correctly rounded quotients (general kernel only; see exact_div() in evc_fused_common.h).
 hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttState& u, int N, int T_,
                          int iters, int first, int write_err, double* err2, int eps_mode, double eps,
-                         double l1, int c_req, int all_live_known, int loss, hipStream_t s) {
+                         double l1, int c_req, int all_live_known, int loss, int exact_div, hipStream_t s) {
     FusedArgs a;
     a.A1p = b.A1p; a.A2p = b.A2p; a.Xp = b.Xp; a.Hp = reinterpret_cast<f64x2*>(b.Hp); a.Vp = b.Vp;
     a.err2 = err2; a.frame_utt = u.frame_utt; a.active = u.active;
     a.NT = f.NT; a.TT = f.TT; a.N = N; a.T_ = T_;
     a.iters = iters; a.first = first; a.write_err = write_err; a.skip_all_live = 0; a.force_live = 0;
-    a.loss = loss;
+    a.loss = loss; a.exact_div = exact_div;
     a.eps_mode = eps_mode; a.eps = eps; a.l1 = l1;
-    const bool resident = c_req == 0 && fused_res_supported(N, eps_mode);
+    const bool resident = c_req == 0 && fused_res_supported(N, eps_mode, exact_div);
     if (!resident) return launch_general(f, a, c_req, s);
     if (first) {                 // V = A H (and the residual at init) by the general kernel's pre-pass
         FusedArgs p = a;
@@ -512,7 +516,7 @@ hipError_t fused_synthesize(const FusedLayout& fB, const double* B2p, const doub
     a.Hp = reinterpret_cast<f64x2*>(const_cast<double*>(Hp)); a.Vp = Yp;
     a.err2 = nullptr; a.frame_utt = u.frame_utt; a.active = u.active;
     a.NT = fB.NT; a.TT = fB.TT; a.N = N; a.T_ = T_;
-    a.iters = 0; a.first = 1; a.write_err = 0; a.skip_all_live = 0; a.force_live = 1; a.loss = EVC_LOSS_FROBENIUS;
+    a.iters = 0; a.first = 1; a.write_err = 0; a.skip_all_live = 0; a.force_live = 1; a.loss = EVC_LOSS_FROBENIUS; a.exact_div = 0;
     a.eps_mode = EVC_EPS_ADD; a.eps = 0; a.l1 = 0;
     hipError_t e = dispatch_msteps<1>(fB.msteps, a, s);
     if (e != hipSuccess) return e;

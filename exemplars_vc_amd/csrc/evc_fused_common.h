@@ -41,6 +41,7 @@ struct FusedArgs {
     int write_err;
     int skip_all_live;       // 1: workgroups whose frames are all live were done by k_fused_res
     int force_live;          // 1: ignore the utterances' active flags (synthesis pre-pass)
+    int exact_div;           // 1: correctly rounded quotients on the fast path too (pymf's 2.2e-16 stop rule)
     int loss;                // EVC_LOSS_*; for KL A1p holds the dictionary pre-divided by its column sums
     int eps_mode;
     double eps, l1;
@@ -62,27 +63,47 @@ struct HTile {
 //   * l1 (and pymf's additive eps) are folded into the initial value of the D accumulator, so
 //     `dacc` arrives as the finished denominator sum;
 //   * one unsigned range test per tile (high words, v_max3) decides between the fast path and the
-//     exact path.  Fast path = every denominator is a normal number in [lo, 2^928): then neither
-//     the ==0 replacement nor the clamp can fire, and the quotient is formed as
-//     r = v_rcp_f64(den) (2^-24.4), one Newton step (2^-48.8 = 2.3e-15 relative, measured by
-//     tools/ubench/rcp_accuracy.hip), q = num*r: 5 VALU per element, no v_div_scale/fmas/fixup and
-//     no selects.  The 10-ulp quotient is the same size as the rounding noise of the N-term
-//     denominator sums next to it; a residual correction would make the quotient correctly
-//     rounded for 2 more VALU per element (2.7 % of the kernel) and moves the end-to-end
-//     difference to the oracle by less than its spread - not taken;
+//     exact path.  Fast path = every denominator is a normal number in [lo, 2^250): then neither
+//     the ==0 replacement nor the clamp can fire, and the four reciprocals of a tile come from ONE
+//     v_rcp_f64 (a quarter-rate instruction) by batch inversion: R = 1/(d0 d1 d2 d3) with one Newton
+//     step (v_rcp_f64 is good to 2^-24.4, one step gives 2.3e-15: tools/ubench/rcp_accuracy.hip),
+//     1/d0 = R (d2 d3) d1 and so on - 3 + 2 + 6 multiplies/FMAs instead of 3 more v_rcp and 6 more
+//     Newton FMAs; products of four numbers in [2^-250, 2^250) cannot leave the normal range.  Then
+//     q = num * (1/d): no v_div_scale/fmas/fixup, no selects.  The quotient's ~3e-15 relative error
+//     is the size of the rounding noise of the N-term denominator sums next to it;
 //   * the exact path (zero / denormal / huge / NaN denominators, and the unguarded NONE mode
 //     always) applies the guard literally and divides with IEEE semantics, so inf/NaN behaviour
 //     is the reference's.
-__device__ __forceinline__ double fast_div(double num, double den) {
+// num/den for a normal den in [2^-250, 2^250): v_rcp_f64, one Newton step, one residual correction.
+// Correctly rounded on every sample of tools/ubench/rcp_accuracy.hip (2^30 quotients): the iteration
+// then reaches the same floating-point fixed points as IEEE division, which pymf's stop rule
+// (|ferr_i - ferr_{i-1}| / T < 2.2e-16, base.py:189-206) needs in order to fire at the same iteration.
+__device__ __forceinline__ double exact_div(double num, double den) {
     double r = __builtin_amdgcn_rcp(den);
     const double e = __builtin_fma(-den, r, 1.0);
     r = __builtin_fma(r, e, r);
-    return num * r;
+    const double qv = num * r;
+    const double rem = __builtin_fma(-den, qv, num);
+    return __builtin_fma(rem, r, qv);
+}
+// 1/d[0..3] for four normal numbers in [2^-250, 2^250)
+__device__ __forceinline__ void batch_rcp(const f64x4& d, double (&r)[4]) {
+    const double a = d[0] * d[1], b = d[2] * d[3];
+    const double ab = a * b;
+    double R = __builtin_amdgcn_rcp(ab);
+    const double e = __builtin_fma(-ab, R, 1.0);
+    R = __builtin_fma(R, e, R);
+    const double Ra = R * b, Rb = R * a;
+    r[0] = Ra * d[1];
+    r[1] = Ra * d[0];
+    r[2] = Rb * d[3];
+    r[3] = Rb * d[2];
 }
 __device__ __forceinline__ unsigned hi_word(double x) { return (unsigned)(__double_as_longlong(x) >> 32); }
-// lowest admissible high word for the fast path: 2^-928, or one binade above eps when clamping
+// lowest admissible high word for the fast path: 2^-250, or one binade above eps when clamping
+constexpr unsigned FAST_HI_WORD = 0x4F900000u;      // 2^250
 __device__ __forceinline__ unsigned fast_lo(int mode, double eps) {
-    unsigned lo = 0x05F00000u;
+    unsigned lo = 0x30500000u;                      // 2^-250
     if (mode == EVC_EPS_CLAMP && eps > 0) {
         const unsigned e = hi_word(eps) + 0x00200000u;
         lo = e > lo ? e : lo;
@@ -91,16 +112,19 @@ __device__ __forceinline__ unsigned fast_lo(int mode, double eps) {
 }
 // MUL_FIRST: pymf / nmf_tool form (h*p)/den, else sklearn / deComP form h*(p/den).  `mode` is only
 // consulted on the exact path.
-template <bool MUL_FIRST, class HT>
+template <bool MUL_FIRST, bool EXACT_DIV = false, class HT>
 __device__ __forceinline__ void mu_tile(HT& h, const f64x4& p, const f64x4& dacc, int mode,
                                         double eps, unsigned lo) {
-    const unsigned span = 0x79F00000u - lo;
+    const unsigned span = FAST_HI_WORD > lo ? FAST_HI_WORD - lo : 0u;
     const unsigned worst = max(max(hi_word(dacc[0]) - lo, hi_word(dacc[1]) - lo),
                                max(hi_word(dacc[2]) - lo, hi_word(dacc[3]) - lo));
     if (__builtin_expect(mode != EVC_EPS_NONE && __all(worst < span), 1)) {
+        double rc[4];
+        if (!EXACT_DIV) batch_rcp(dacc, rc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const double qv = fast_div(MUL_FIRST ? h[r] * p[r] : p[r], dacc[r]);
+            const double num = MUL_FIRST ? h[r] * p[r] : p[r];
+            const double qv = EXACT_DIV ? exact_div(num, dacc[r]) : num * rc[r];
             h[r] = MUL_FIRST ? qv : h[r] * qv;
         }
     } else {
@@ -124,6 +148,6 @@ __device__ __forceinline__ double kl_terms(double x, double v, double eps) {
     if (x > eps) e += x * log(x / (v < eps ? eps : v)) - x;
     return 2.0 * e;
 }
-bool fused_res_supported(int N, int eps_mode);
+bool fused_res_supported(int N, int eps_mode, int exact_div);
 
 }  // namespace evc

@@ -310,8 +310,8 @@ static hipError_t pick_loss(const FusedArgs& a, hipStream_t s) {
     return a.loss == EVC_LOSS_KL ? pick_res<MSTEPS, true>(a, s) : pick_res<MSTEPS, false>(a, s);
 }
 
-bool fused_res_supported(int N, int eps_mode) {
-    return (N % 128 == 0) && (N / 128 >= 8) && eps_mode != EVC_EPS_NONE;
+bool fused_res_supported(int N, int eps_mode, int exact_div) {
+    return (N % 128 == 0) && (N / 128 >= 8) && eps_mode != EVC_EPS_NONE && !exact_div;
 }
 
 hipError_t fused_res_launch(int msteps, const FusedArgs& a, hipStream_t s) {

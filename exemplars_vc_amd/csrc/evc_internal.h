@@ -160,7 +160,7 @@ hipError_t fused_synthesize(const FusedLayout& fB, const double* B2p, const doub
 // Vp from the previous launch); write_err: per-frame squared residuals of the final H -> err2.
 hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttState& u, int N, int T_,
                          int iters, int first, int write_err, double* err2, int eps_mode, double eps,
-                         double l1, int c_req, int all_live_known, int loss, hipStream_t s);
+                         double l1, int c_req, int all_live_known, int loss, int exact_div, hipStream_t s);
 
 // ----- evc_gl.hip -----
 size_t gl_workspace_bytes(int T_, int F, int hop, int iters);
