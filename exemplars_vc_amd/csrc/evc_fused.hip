@@ -385,7 +385,10 @@ FusedLayout fused_layout(int M, int N, int T_) {
     FusedLayout f;
     f.msteps = fused_msteps(M);
     f.mtiles = M > 16 ? 2 : 1;
-    f.NT = (N + 15) / 16;
+    // from 1024 exemplars on (k_fused_res: 8 wavefronts x >= 8 tiles) the tile count is padded to whole
+    // rounds of the 8 wavefronts; padding exemplars have zero dictionary columns and zero activations, and
+    // 0 * 0 / guard keeps them at zero under every guarded eps mode
+    f.NT = N >= 1024 ? round_up(N, 128) / 16 : (N + 15) / 16;
     f.TT = (T_ + 15) / 16;
     f.TTp = round_up(f.TT, 4);
     f.a1 = (size_t)f.NT * ((f.msteps + 1) & ~1) * 64;

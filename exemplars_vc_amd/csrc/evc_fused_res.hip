@@ -13,7 +13,8 @@
 //     has issued (its operand registers are free from then on).
 //
 // This kernel is the straight-line fast path only; it requires
-//   N % 128 == 0 and N / 128 >= 2*RES   (every wavefront owns the same number of tiles),
+//   N >= 1024 (fused_layout pads the tile count to whole rounds of the 8 wavefronts from there on:
+//   every wavefront owns the same number of tiles, >= 2*RES; padding exemplars are all-zero),
 //   a guarded eps mode (not NONE),
 //   every frame of the workgroup live (utterance still active) - otherwise the workgroup
 //   returns immediately and evc_fused.hip's kernel, launched behind it with skip_all_live = 1,
@@ -311,7 +312,7 @@ static hipError_t pick_loss(const FusedArgs& a, hipStream_t s) {
 }
 
 bool fused_res_supported(int N, int eps_mode, int exact_div) {
-    return (N % 128 == 0) && (N / 128 >= 8) && eps_mode != EVC_EPS_NONE && !exact_div;
+    return N >= 1024 && eps_mode != EVC_EPS_NONE && !exact_div;      // fused_layout pads N to 128 from there on
 }
 
 hipError_t fused_res_launch(int msteps, const FusedArgs& a, hipStream_t s) {

@@ -247,12 +247,13 @@ def test_convert_is_solve_then_synthesize(M, Mb, N, T, layout):
     assert_close64(Yc if layout == "bin_major" else Yc.T, want, "Y only")
 
 
-@pytest.mark.parametrize("N", [1024, 2048, 4096, 1152])
+@pytest.mark.parametrize("N", [1024, 2048, 4096, 1152, 1031, 4001])
 @pytest.mark.parametrize("eps_mode,eps,l1", [("add", 1e-9, 0.0), ("zero_replace", 1.1920929e-7, 0.0),
                                               ("clamp", 1e-15, 0.0), ("zero_replace", 1.1920929e-7, 0.3)])
 def test_register_resident_kernel_modes(N, eps_mode, eps, l1):
-    """k_fused_res runs for N % 128 == 0, N >= 1024 (4, 8 or 16 resident tiles per wavefront; N = 1152 has
-    a streamed tail beyond the resident window).  Every guarded mode, ragged T (padded frames), zero
+    """k_fused_res runs for N >= 1024 (4, 8 or 16 resident tiles per wavefront; N = 1152 has a streamed
+    tail beyond the resident window; N = 1031 / 4001 are padded to a multiple of 128 with zero exemplars,
+    which must stay exactly zero and out of the result).  Every guarded mode, ragged T (padded frames), zero
     frames (exact path of the update) and an absorbing zero row, against the oracle."""
     import exemplars_vc_amd as evc
     o = oracle()
