@@ -9,7 +9,7 @@ using namespace evc;
 
 namespace {
 
-enum { ST_OK = 0, ST_BADARG = -1, ST_WORKSPACE = -2, ST_UNSUPPORTED = -3 };
+enum { ST_OK = 0, ST_BADARG = -1, ST_WORKSPACE = -2, ST_UNSUPPORTED = -3, ST_COOP_TIMEOUT = -4 };
 
 struct Carver {
     char* base;
@@ -85,6 +85,9 @@ Workspace<T> carve(void* base, const Dims& d, int algo, int n_slots, bool fused)
         w.fb.Xp = c.take<double>(w.fl.xp);
         w.fb.Hp = c.take<double>(w.fl.hp);
         w.fb.Vp = c.take<double>(w.fl.vp);
+        w.fb.coop_buf = c.take<double>((size_t)2 * COOP_MAX_TILES * 512);
+        w.fb.coop_cnt = c.take<int>(COOP_MAX_TILES + 1);
+        w.fb.coop_c = 1;
     }
     w.flB = FusedLayout{};
     w.Bt = nullptr; w.B1p = w.B2p = w.Yp = nullptr;
@@ -175,9 +178,21 @@ int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_sol
         HIP_TRY(fused_pack_dict(w.fl, w.fb.A1p, w.fb.A2p, w.At, d.Mk, s));
     }
     HIP_TRY(fused_pack_frames(w.fl, w.fb.Xp, w.Xt, d.Mk, s));
+    // few frame tiles (one or two utterances): several workgroups share a tile and split the exemplars
+    // (k_fused_res COOP); reserved bit 2 switches it off
+    FusedBuffers fb = w.fb;
+    fb.coop_c = 1;
+    if (!(o.reserved & 4) && c_override == 0 && fused_res_supported(d.N, o.eps_mode, exact_div)) {
+        int dev = 0, cus = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        fb.coop_c = fused_res_coop_factor(w.fl.NT, w.fl.TT, cus);
+    }
+    int* coop_abort = fb.coop_cnt + COOP_MAX_TILES;
+    if (fb.coop_c > 1) HIP_TRY(hipMemsetAsync(coop_abort, 0, sizeof(int), s));
     int first = 1;
     if (o.check_every > 0 && o.stop_rule == EVC_STOP_SKLEARN) {   // error_at_init
-        HIP_TRY(fused_iterate(w.fl, w.fb, w.u, d.N, d.T_, 0, 1, 1, w.err2, o.eps_mode, o.eps, o.l1,
+        HIP_TRY(fused_iterate(w.fl, fb, w.u, d.N, d.T_, 0, 1, 1, w.err2, o.eps_mode, o.eps, o.l1,
                               c_override, 1, o.loss, exact_div, s));
         HIP_TRY(utt_check(w.err2, w.u, n_utt, 0, o.check_every, o.stop_rule, o.tol, s));
         first = 0;
@@ -188,7 +203,7 @@ int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_sol
         int n = o.iters - done;
         bool check = false;
         if (o.check_every > 0 && n >= o.check_every) { n = o.check_every; check = true; }
-        HIP_TRY(fused_iterate(w.fl, w.fb, w.u, d.N, d.T_, n, first, check ? 1 : 0, w.err2, o.eps_mode,
+        HIP_TRY(fused_iterate(w.fl, fb, w.u, d.N, d.T_, n, first, check ? 1 : 0, w.err2, o.eps_mode,
                               o.eps, o.l1, c_override, o.stop_rule == EVC_STOP_NONE ? 1 : 0, o.loss, exact_div, s));
         first = 0;
         done += n;
@@ -197,6 +212,12 @@ int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_sol
                               o.tol, s));
     }
     if (o.ev_loop_stop) HIP_TRY(hipEventRecord((hipEvent_t)o.ev_loop_stop, s));
+    if (fb.coop_c > 1) {        // a cooperative launch that gave up waiting leaves void results: report it
+        int aborted = 0;
+        HIP_TRY(hipMemcpyAsync(&aborted, coop_abort, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (aborted) return ST_COOP_TIMEOUT;
+    }
     return ST_OK;
 }
 
@@ -366,6 +387,7 @@ const char* evc_strerror(int status) {
         case ST_BADARG: return "invalid argument";
         case ST_WORKSPACE: return "workspace too small (see evc_workspace_bytes)";
         case ST_UNSUPPORTED: return "unsupported option combination";
+        case ST_COOP_TIMEOUT: return "cooperative launch timed out waiting for a peer workgroup (results void)";
         default: break;
     }
     if (status > 0) return hipGetErrorString((hipError_t)status);
@@ -461,7 +483,16 @@ int evc_synthesize(const void* B, int ldb, const void* H, int ldh, void* Y, int 
         return ST_BADARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipError_t e;
-    if (layout == EVC_FRAME_MAJOR) {
+    if (Mb <= 64) {     // a handful of bins: one pass over H, wavefronts split the exemplars (k_synth_skinny)
+        const bool fm = layout == EVC_FRAME_MAJOR;
+        // FRAME_MAJOR: H[t][n], B[n][mb], Y[t][mb];  BIN_MAJOR: H[n][t], B[mb][n], Y[mb][t]
+        const long hst = fm ? ldh : 1, hsn = fm ? 1 : ldh, bsn = fm ? ldb : 1, bsm = fm ? 1 : ldb;
+        const long yst = fm ? ldy : 1, ysm = fm ? 1 : ldy;
+        if (dtype == EVC_F64)
+            e = synth_skinny<double>((const double*)H, hst, hsn, (const double*)B, bsn, bsm, (double*)Y, yst, ysm, T, Mb, N, s);
+        else
+            e = synth_skinny<float>((const float*)H, hst, hsn, (const float*)B, bsn, bsm, (float*)Y, yst, ysm, T, Mb, N, s);
+    } else if (layout == EVC_FRAME_MAJOR) {
         // Y[t][mb] = sum_n H[t][n] B[n][mb]           (np.matmul(H.T, B), 04_align_n_nmf.py:391)
         if (dtype == EVC_F64)
             e = gemm_strided<double>((const double*)H, ldh, 1, (const double*)B, 1, ldb, (double*)Y, ldy, 1, T, Mb, N, s);

@@ -492,6 +492,7 @@ hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttS
     a.iters = iters; a.first = first; a.write_err = write_err; a.skip_all_live = 0; a.force_live = 0;
     a.loss = loss; a.exact_div = exact_div;
     a.eps_mode = eps_mode; a.eps = eps; a.l1 = l1;
+    a.coop_c = 1; a.coop_buf = nullptr; a.coop_cnt = nullptr; a.coop_abort = nullptr;
     const bool resident = c_req == 0 && fused_res_supported(N, eps_mode, exact_div);
     if (!resident) return launch_general(f, a, c_req, s);
     if (first) {                 // V = A H (and the residual at init) by the general kernel's pre-pass
@@ -503,6 +504,10 @@ hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttS
         a.first = 0;
     }
     if (iters == 0) return hipSuccess;
+    if (b.coop_c > 1 && b.coop_buf && b.coop_cnt) {
+        a.coop_c = b.coop_c; a.coop_buf = b.coop_buf; a.coop_cnt = b.coop_cnt;
+        a.coop_abort = b.coop_cnt + COOP_MAX_TILES;
+    }
     hipError_t e = fused_res_launch(f.msteps, a, s);
     if (e != hipSuccess || all_live_known) return e;
     a.skip_all_live = 1;         // workgroups holding frames of stopped utterances
@@ -520,6 +525,7 @@ hipError_t fused_synthesize(const FusedLayout& fB, const double* B2p, const doub
     a.err2 = nullptr; a.frame_utt = u.frame_utt; a.active = u.active;
     a.NT = fB.NT; a.TT = fB.TT; a.N = N; a.T_ = T_;
     a.iters = 0; a.first = 1; a.write_err = 0; a.skip_all_live = 0; a.force_live = 1; a.loss = EVC_LOSS_FROBENIUS; a.exact_div = 0;
+    a.coop_c = 1; a.coop_buf = nullptr; a.coop_cnt = nullptr; a.coop_abort = nullptr;
     a.eps_mode = EVC_EPS_ADD; a.eps = 0; a.l1 = 0;
     hipError_t e = dispatch_msteps<1>(fB.msteps, a, s);
     if (e != hipSuccess) return e;

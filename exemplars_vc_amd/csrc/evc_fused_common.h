@@ -45,6 +45,12 @@ struct FusedArgs {
     int loss;                // EVC_LOSS_*; for KL A1p holds the dictionary pre-divided by its column sums
     int eps_mode;
     double eps, l1;
+    // cooperative launch (k_fused_res, few frame tiles): coop_c workgroups share one 16-frame tile, each owning
+    // NT / coop_c exemplar tiles; they exchange their V' partials through coop_buf once per iteration
+    int coop_c;              // 1 = off
+    double* coop_buf;        // [2][TT][coop_c][E]
+    int* coop_cnt;           // [TT] arrival counters, zero at launch
+    int* coop_abort;         // set when a wait timed out: the launch's results are void
 };
 
 // One tile's four activations of a lane.  The elements sit 16 bytes apart on purpose: stored back to
@@ -148,6 +154,5 @@ __device__ __forceinline__ double kl_terms(double x, double v, double eps) {
     if (x > eps) e += x * log(x / (v < eps ? eps : v)) - x;
     return 2.0 * e;
 }
-bool fused_res_supported(int N, int eps_mode, int exact_div);
 
 }  // namespace evc

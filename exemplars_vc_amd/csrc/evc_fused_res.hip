@@ -38,7 +38,23 @@ constexpr int RNW = 8;    // wavefronts per workgroup
 
 // KL: the generalised Kullback-Leibler update (A1p holds the dictionary divided by its column sums; the
 // per-unit work is one MFMA chain (A_j/colsum)^T (X / max(V, eps)) and a multiply, no division).
-template <int MSTEPS, int RES, int PL, bool KL>
+//
+// COOP (few frame tiles, e.g. one utterance = 43 workgroups on 256 CUs): coop_c workgroups share one frame
+// tile, workgroup `member` owning exemplar tiles [member NT/c, (member+1) NT/c).  After the intra-workgroup
+// combine every thread publishes its element of the partial V' with an agent-scope atomic store (these bypass
+// the per-XCD L2 both ways; an agent-scope release/acquire pair instead would write back and invalidate the
+// whole L2 every iteration and lose the dictionary fragments cached there - measured 45 us per iteration) and
+// polls the same element of its peers.  There is no separate flag: the lowest mantissa bit of the word is the
+// buffer's epoch (readers clear it), so one memory round trip carries data and arrival; a counter + data
+// protocol costs five serialised round trips (measured 19 us per iteration against 9 us of compute).  All
+// members sum the c words in member order and obtain the bitwise identical V'.  Two buffers alternate by
+// iteration parity: a member writes iteration i+2 only after it has read every peer's word of iteration i+1,
+// which the peer wrote after reading this member's word of iteration i.  The host launches TT*c <= #CUs
+// workgroups of one-per-CU size, so all members are resident; a poll budget bounds every wait, and a
+// workgroup that exhausts it raises coop_abort, on which all leave (no hang; the host reports the launch void).
+constexpr unsigned COOP_POLL_LIMIT = 1u << 22;
+
+template <int MSTEPS, int RES, int PL, bool KL, bool COOP = false>
 __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
     constexpr int MT = MSTEPS > 4 ? 2 : 1;
     constexpr int E = MT * 4 * 64;               // doubles in one V (accumulator order)
@@ -52,12 +68,15 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
     f64x2* pL = reinterpret_cast<f64x2*>(rL + E) + (size_t)(threadIdx.x >> 6) * (PL * 128);   // [PL][2][64] per wavefront
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const long tt = blockIdx.x;
+    const int cc = COOP ? a.coop_c : 1;
+    const long tt = COOP ? blockIdx.x / cc : blockIdx.x;
+    const int member = COOP ? (int)(blockIdx.x % cc) : 0;
     const double* __restrict__ A1p = a.A1p;
     const double* __restrict__ A2p = a.A2p;
     f64x2* __restrict__ Hp = a.Hp;
     const int NT = a.NT;
-    const int KT = NT / RNW;                     // tiles per wavefront (host guarantees >= 2*RES)
+    const int KT = NT / cc / RNW;                // tiles per wavefront (host guarantees >= 2*RES)
+    const long tile0 = (long)member * (NT / cc);  // first exemplar tile of this workgroup
 
     {
         const long t = 16 * tt + (lane & 15);
@@ -87,9 +106,9 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
     const unsigned ul = (unsigned)lane;
     long sw = 0;
     constexpr int MSP = (MSTEPS + 1) & ~1;                            // k-steps padded to pairs in A1p
-    const long a1w = (long)w * MSP * 64;                              // tile k: + k * RNW*MSP*64
-    const long a2w = (long)w * MT * 256;                              // tile k: + k * RNW*MT*256
-    const long hw = (tt * NT + w) * 128;                              // tile k: + k * RNW*128
+    const long a1w = (tile0 + w) * MSP * 64;                          // tile k: + k * RNW*MSP*64
+    const long a2w = (tile0 + w) * MT * 256;                          // tile k: + k * RNW*MT*256
+    const long hw = (tt * NT + tile0 + w) * 128;                      // tile k: + k * RNW*128
     auto load_a1 = [&](double (&a1)[MSTEPS], int k) {
         const f64x2* t = reinterpret_cast<const f64x2*>(A1p + (a1w + sw + (long)k * (RNW * MSP * 64)));
 #pragma unroll
@@ -250,20 +269,60 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) red[w * E + (u * 4 + r) * 64 + lane] = vn[u][r];
         __syncthreads();
+        long long* slot = nullptr;
+        if (COOP) slot = reinterpret_cast<long long*>(a.coop_buf) + ((size_t)(it & 1) * a.TT + tt) * cc * E;
+        const long long tag = (it >> 1) & 1;       // a buffer is reused every second iteration: its epoch bit flips
+        bool ok = true;
         for (int e = w * 64 + lane; e < E; e += RNW * 64) {
             double acc = 0.0;
 #pragma unroll
             for (int ww = 0; ww < RNW; ++ww) acc += red[ww * E + e];
+            if (COOP) {
+                // publish: the value with its lowest mantissa bit replaced by the epoch bit (readers clear it again,
+                // so every member - this one included - sums the same c numbers, each within 1 ulp of the partial)
+                const long long mine = (__double_as_longlong(acc) & ~1LL) | tag;
+                __hip_atomic_store(slot + (size_t)member * E + e, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // gather: poll the peers' words until they carry this epoch (stale words carry the other bit: the
+                // host fills the buffers with ones before the launch, iterations 2k and 2k+1 write epoch k & 1)
+                double sum = 0.0;
+                for (int m0 = 0; m0 < cc; m0 += 2) {
+                    long long b0 = mine, b1 = mine;
+                    unsigned polls = 0;
+                    for (;;) {
+                        if (m0 != member) b0 = __hip_atomic_load(slot + (size_t)m0 * E + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (m0 + 1 != member) b1 = __hip_atomic_load(slot + (size_t)(m0 + 1) * E + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (((b0 & 1) == tag) && ((b1 & 1) == tag)) break;
+                        if (++polls > COOP_POLL_LIMIT ||
+                            ((polls & 1023) == 0 &&
+                             __hip_atomic_load(a.coop_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                            ok = false;
+                            break;
+                        }
+                    }
+                    if (!ok) break;
+                    sum += __longlong_as_double(b0 & ~1LL);       // member order: identical on every member
+                    sum += __longlong_as_double(b1 & ~1LL);
+                }
+                acc = sum;
+            }
             vL[e] = acc;
             if (KL) rL[e] = xL[e] / (acc < a.eps ? a.eps : acc);     // sklearn _nmf.py:572-576
         }
-        __syncthreads();
+        if (COOP) {
+            if (!__syncthreads_and(ok)) {        // a peer never showed up: void the launch, let everybody leave
+                if (tid == 0) __hip_atomic_store(a.coop_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+        } else {
+            __syncthreads();
+        }
     }
 
 #pragma unroll
     for (int k = 0; k < RES; ++k) store_h(hres[k], 2 * k);
 
     // carry V to the next launch; per-frame squared residual of the final activations
+    if (COOP && member != 0) return;             // every member holds the same V: one writes it
     for (int e = tid; e < E; e += RNW * 64) {
         const int s = e >> 6, l = e & 63;
         if (s < MSTEPS) a.Vp[(tt * 8 + s) * 64 + l] = vL[e];
@@ -282,28 +341,51 @@ __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {
     }
 }
 
-template <int MSTEPS, int RES, bool KL>
+template <int MSTEPS, int RES, bool KL, bool COOP>
 static hipError_t launch_res(const FusedArgs& a, hipStream_t s) {
     constexpr int MT = MSTEPS > 4 ? 2 : 1;
     constexpr int E = MT * 4 * 64;
     constexpr int PL = KL ? 0 : EVC_RES_PL;
     const size_t lds = (size_t)(RNW + 3) * E * sizeof(double) + (size_t)RNW * PL * 256 * sizeof(double);
     if (lds > 64 * 1024) {   // per launch: no mutable global state is kept
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_res<MSTEPS, RES, PL, KL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_res<MSTEPS, RES, PL, KL, COOP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_fused_res<MSTEPS, RES, PL, KL>), dim3((unsigned)a.TT), dim3(RNW * 64), lds, s, a);
+    const unsigned grid = (unsigned)a.TT * (COOP ? (unsigned)a.coop_c : 1u);
+    hipLaunchKernelGGL((k_fused_res<MSTEPS, RES, PL, KL, COOP>), dim3(grid), dim3(RNW * 64), lds, s, a);
     return hipGetLastError();
 }
 
 template <int MSTEPS, bool KL>
 static hipError_t pick_res(const FusedArgs& a, hipStream_t s) {
+    if (a.coop_c > 1) {
+        // cooperative: NT / coop_c / 8 tiles per wavefront (the host picked coop_c so that this is >= 8)
+        if (!a.coop_buf || !a.coop_cnt || !a.coop_abort || a.NT % (a.coop_c * RNW)) return hipErrorInvalidValue;
+        if ((long)a.TT * a.coop_c > COOP_MAX_TILES) return hipErrorInvalidValue;
+        // stale words must not carry the epoch bit of the first two iterations (0): fill with ones
+        hipError_t e = hipMemsetAsync(a.coop_buf, 0xFF, sizeof(double) * 2 * a.TT * a.coop_c * 512, s);
+        if (e != hipSuccess) return e;
+        const int KT = a.NT / a.coop_c / RNW;
+        if (KT >= 2 * EVC_RES_MAX) return launch_res<MSTEPS, EVC_RES_MAX, KL, true>(a, s);
+        if (KT >= 16) return launch_res<MSTEPS, 8, KL, true>(a, s);
+        if (KT >= 8) return launch_res<MSTEPS, 4, KL, true>(a, s);
+        return hipErrorInvalidValue;
+    }
     const int KT = a.NT / RNW;
-    if (KT >= 2 * EVC_RES_MAX) return launch_res<MSTEPS, EVC_RES_MAX, KL>(a, s);
-    if (KT >= 16) return launch_res<MSTEPS, 8, KL>(a, s);
-    if (KT >= 8) return launch_res<MSTEPS, 4, KL>(a, s);
+    if (KT >= 2 * EVC_RES_MAX) return launch_res<MSTEPS, EVC_RES_MAX, KL, false>(a, s);
+    if (KT >= 16) return launch_res<MSTEPS, 8, KL, false>(a, s);
+    if (KT >= 8) return launch_res<MSTEPS, 4, KL, false>(a, s);
     return hipErrorInvalidValue;
+}
+
+// Largest power-of-two number of cooperating workgroups per frame tile such that every workgroup is resident
+// (one per CU), every wavefront still owns >= 8 exemplar tiles, and at least half of the CUs would idle without it.
+int fused_res_coop_factor(int NT, int TT, int n_cus) {
+    if (n_cus > COOP_MAX_TILES) n_cus = COOP_MAX_TILES;
+    int c = 1;
+    while (2 * c * TT <= n_cus && NT % (2 * c * RNW) == 0 && NT / (2 * c * RNW) >= 8) c *= 2;
+    return c;
 }
 
 template <int MSTEPS>

@@ -224,18 +224,32 @@ __global__ __launch_bounds__(256) void k_gemm_strided(const T* __restrict__ L, l
     for (int a = 0; a < 2; ++a)
         for (int b = 0; b < 2; ++b) acc[a][b] = acc_t{0, 0, 0, 0};
 
+    // element (row, k) of the slab each thread stages: along k when k is the contiguous direction
+    int lrow[4], lk[4], rrow[4], rk[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (lsk == 1) { lk[e] = tid & 15; lrow[e] = (tid >> 4) + 16 * e; } else { lrow[e] = tid & 63; lk[e] = (tid >> 6) + 4 * e; }
+        if (rsk == 1) { rk[e] = tid & 15; rrow[e] = (tid >> 4) + 16 * e; } else { rrow[e] = tid & 63; rk[e] = (tid >> 6) + 4 * e; }
+    }
+    T pl[4], pr[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const long gi = bi + lrow[e], gk = k0 + lk[e];
+            pl[e] = (gi < I && gk < Kd) ? L[gi * lsi + gk * lsk] : T(0);
+            const long gj = bj + rrow[e], gk2 = k0 + rk[e];
+            pr[e] = (gj < J && gk2 < Kd) ? R[gj * rsj + gk2 * rsk] : T(0);
+        }
+    };
+    fetch(0);
     for (int k0 = 0; k0 < Kd; k0 += KS) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            int row, k;
-            if (lsk == 1) { k = tid & 15; row = (tid >> 4) + 16 * e; } else { row = tid & 63; k = (tid >> 6) + 4 * e; }
-            const long gi = bi + row, gk = k0 + k;
-            sL[k][row] = (gi < I && gk < Kd) ? L[gi * lsi + gk * lsk] : T(0);
-            if (rsk == 1) { k = tid & 15; row = (tid >> 4) + 16 * e; } else { row = tid & 63; k = (tid >> 6) + 4 * e; }
-            const long gj = bj + row, gk2 = k0 + k;
-            sR[k][row] = (gj < J && gk2 < Kd) ? R[gj * rsj + gk2 * rsk] : T(0);
+            sL[lk[e]][lrow[e]] = pl[e];
+            sR[rk[e]][rrow[e]] = pr[e];
         }
         __syncthreads();
+        if (k0 + KS < Kd) fetch(k0 + KS);      // the next slab's loads fly while this one is multiplied
 #pragma unroll
         for (int st = 0; st < KS / 4; ++st) {
             const int kk = 4 * st + q;
@@ -270,11 +284,89 @@ hipError_t gemm_strided(const T* L, long lsi, long lsk, const T* R, long rsj, lo
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// synthesis Y = B H for a handful of bins (Mb <= 64) and a long contraction (N exemplars): tall and
+// skinny, bound by the single pass over H.  One workgroup per 16 frames; its 8 wavefronts split N, each
+// accumulating 16 x 16 output tiles straight from global memory (a lane reads 4 consecutive exemplars
+// of its frame, which feed 4 MFMA k-steps), then a fixed-order LDS reduction.  Caller strides.
+//   H(t, n) = H[t hst + n hsn],  B(n, mb) = B[n bsn + mb bsm],  Y(t, mb) = Y[t yst + mb ysm]
+// ------------------------------------------------------------------------------------------
+constexpr int SYN_WAVES = 8;
+constexpr int SYN_MAX_MB = 64;
+
+template <typename T, int MT>
+__global__ __launch_bounds__(SYN_WAVES * 64) void k_synth_skinny(const T* __restrict__ H, long hst, long hsn,
+                                                                const T* __restrict__ B, long bsn, long bsm,
+                                                                T* __restrict__ Y, long yst, long ysm, int T_,
+                                                                int Mb, int N) {
+    typedef typename Mma<T>::acc_t acc_t;
+    __shared__ T red[SYN_WAVES][MT][4][64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i16 = lane & 15, q = lane >> 4;
+    const long t = (long)blockIdx.x * 16 + i16;
+    acc_t acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[m] = acc_t{0, 0, 0, 0};
+    const int tiles = (N + 15) / 16;
+    const int per = (tiles + SYN_WAVES - 1) / SYN_WAVES;
+    const int j1 = min(tiles, (w + 1) * per);
+    const bool t_ok = t < T_;
+    for (int j = w * per; j < j1; ++j) {
+        const long n0 = 16L * j + 4 * q;              // this lane's 4 exemplars: n0 .. n0+3 <-> k-steps 0..3
+        T hv[4], bv[MT][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bool n_ok = n0 + s < N;
+            hv[s] = (t_ok && n_ok) ? H[t * hst + (n0 + s) * hsn] : T(0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int mb = 16 * m + i16;
+                bv[m][s] = (n_ok && mb < Mb) ? B[(n0 + s) * bsn + mb * bsm] : T(0);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = Mma<T>::mma(hv[s], bv[m][s], acc[m]);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[w][m][r][lane] = acc[m][r];
+    __syncthreads();
+    for (int e = tid; e < MT * 256; e += SYN_WAVES * 64) {
+        const int m = e >> 8, r = (e >> 6) & 3, l = e & 63;
+        T v = T(0);
+#pragma unroll
+        for (int ww = 0; ww < SYN_WAVES; ++ww) v += red[ww][m][r][l];
+        const long tr = (long)blockIdx.x * 16 + Mma<T>::row(l, r);     // accumulator row = frame
+        const int mb = 16 * m + (l & 15);
+        if (tr < T_ && mb < Mb) Y[tr * yst + mb * ysm] = v;
+    }
+}
+
+template <typename T>
+hipError_t synth_skinny(const T* H, long hst, long hsn, const T* B, long bsn, long bsm, T* Y, long yst,
+                        long ysm, int T_, int Mb, int N, hipStream_t s) {
+    if (T_ <= 0 || Mb <= 0) return hipSuccess;
+    if (Mb > SYN_MAX_MB) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((T_ + 15) / 16)), block(SYN_WAVES * 64);
+    switch ((Mb + 15) / 16) {
+        case 1: hipLaunchKernelGGL((k_synth_skinny<T, 1>), grid, block, 0, s, H, hst, hsn, B, bsn, bsm, Y, yst, ysm, T_, Mb, N); break;
+        case 2: hipLaunchKernelGGL((k_synth_skinny<T, 2>), grid, block, 0, s, H, hst, hsn, B, bsn, bsm, Y, yst, ysm, T_, Mb, N); break;
+        case 3: hipLaunchKernelGGL((k_synth_skinny<T, 3>), grid, block, 0, s, H, hst, hsn, B, bsn, bsm, Y, yst, ysm, T_, Mb, N); break;
+        default: hipLaunchKernelGGL((k_synth_skinny<T, 4>), grid, block, 0, s, H, hst, hsn, B, bsn, bsm, Y, yst, ysm, T_, Mb, N); break;
+    }
+    return hipGetLastError();
+}
+
 #define EVC_INST(T)                                                                                  \
     template hipError_t gemm_nt<T>(const T*, int, const T*, int, T*, int, int, int, int, hipStream_t, T*, size_t); \
     template hipError_t gemm_nt_mu<T>(const T*, int, const T*, int, T*, int, int, int,                \
                                       const MuEpilogue<T>&, hipStream_t);                            \
     template hipError_t gemm_strided<T>(const T*, long, long, const T*, long, long, T*, long, long,  \
+                                        int, int, int, hipStream_t);                                  \
+    template hipError_t synth_skinny<T>(const T*, long, long, const T*, long, long, T*, long, long,  \
                                         int, int, int, hipStream_t);
 EVC_INST(double)
 EVC_INST(float)

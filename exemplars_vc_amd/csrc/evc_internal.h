@@ -95,6 +95,10 @@ hipError_t gemm_nt_mu(const T* L, int ldl, const T* R, int ldr, T* Hout, int I, 
 template <typename T>
 hipError_t gemm_strided(const T* L, long lsi, long lsk, const T* R, long rsj, long rsk, T* C,
                         long csi, long csj, int I, int J, int Kd, hipStream_t s);
+// Y = B H for Mb <= 64 bins (evc_synthesize): H(t,n) = H[t hst + n hsn], B(n,mb) = B[n bsn + mb bsm], Y(t,mb) = Y[t yst + mb ysm]
+template <typename T>
+hipError_t synth_skinny(const T* H, long hst, long hsn, const T* B, long bsn, long bsm, T* Y, long yst,
+                        long ysm, int T_, int Mb, int N, hipStream_t s);
 
 // ----- evc_aux.hip -----
 // dst (dst_rows x dst_cols, row stride dst_ld) = src (src_rows x src_cols), zero outside src.
@@ -136,8 +140,14 @@ struct FusedLayout {
     int mtiles;          // 1 (M <= 16) or 2
     size_t a1, a2, xp, hp, vp;   // element counts of the packed arrays
 };
+constexpr int COOP_MAX_TILES = 256;       // frame tiles x cooperating workgroups never exceeds this (one per CU)
+int fused_res_coop_factor(int NT, int TT, int n_cus);
+bool fused_res_supported(int N, int eps_mode, int exact_div);
 struct FusedBuffers {
     double *A1p, *A2p, *Xp, *Hp, *Vp;
+    double* coop_buf;      // exchange buffers of the cooperative launch (see k_fused_res)
+    int* coop_cnt;         // [COOP_MAX_TILES] arrival counters, then one abort flag
+    int coop_c;            // cooperating workgroups per frame tile chosen for this call (1 = off)
 };
 bool fused_supported(int M, int N, int T_, int dtype);
 FusedLayout fused_layout(int M, int N, int T_);

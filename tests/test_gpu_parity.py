@@ -381,9 +381,15 @@ def test_c2_full_size_properties():
                        utt_offsets=[0, 688, 1376, T])
     assert (H >= 0).all() and np.isfinite(H).all()
     assert_close64(Y, p["B"] @ H, "Y = B H at full size", rtol=1e-10)
-    # frames 0..687 form utterance 0: identical to solving that utterance alone
-    H0 = evc.solve_activations(p["A"], p["X"][:, :688], iters=K, eps_mode="zero_replace", init="sklearn")
-    assert np.array_equal(H[:, :688], H0)
+    # frames 0..687 form utterance 0: bitwise identical to solving that utterance alone with the same launch
+    # mode (one workgroup per 16 frames); a lone utterance by default takes the cooperative launch, which sums
+    # V' in another order
+    kw0 = dict(iters=K, eps_mode="zero_replace", init="sklearn")
+    H0 = evc.solve_activations(p["A"], p["X"][:, :688], cooperative=False, **kw0)
+    Hb = evc.solve_activations(p["A"], p["X"], utt_offsets=[0, 688, 1376, T], cooperative=False, **kw0)
+    assert np.array_equal(Hb[:, :688], H0)
+    assert_close64(H[:, :688], H0, "cooperative vs one workgroup per tile", rtol=1e-10)
+    H0 = evc.solve_activations(p["A"], p["X"][:, :688], **kw0)
     # entry-by-entry against the float64 oracle on 48 frames of utterance 0 (same init value)
     avg = np.sqrt(p["X"][:, :688].mean() / N)
     want = o.mu_solve(p["A"], p["X"][:, :48], np.full((N, 48), avg), K, eps_mode=o.EPS_ZERO_REPLACE,
@@ -515,3 +521,77 @@ def test_float32_factorize_surface():
     want, n, _ = o.sklearn_mu_fixed_dictionary(X, W, 150, 0.0)
     assert H.dtype == np.float32 and want.dtype == np.float32
     np.testing.assert_allclose(H, want.T, rtol=5e-3, atol=1e-5 * float(want.max()))
+
+
+@pytest.mark.parametrize("N,T", [(4096, 688), (4096, 37), (2048, 100), (16384, 20), (4001, 50)])
+@pytest.mark.parametrize("eps_mode,eps", [("zero_replace", 1.1920929e-7), ("add", 1e-9)])
+def test_cooperative_launch_matches_single_workgroup_tiles(N, T, eps_mode, eps):
+    """One or two utterances leave most CUs idle with one workgroup per 16 frames; k_fused_res then runs
+    cooperatively (several workgroups share a frame tile, split the exemplars and exchange V' through
+    global memory every iteration).  Same result as the non-cooperative launch up to summation order, and
+    both against the oracle; zero frames and an absorbing zero row included."""
+    import exemplars_vc_amd as evc
+    o = oracle()
+    M, K = 25, 30
+    p = o.synth_problem(M, N, T, seed=N + T)
+    X = p["X"].copy()
+    X[:, 3] = 0.0
+    H0 = np.random.default_rng(N).random((N, T)) + 1e-4
+    H0[5, :] = 0.0
+    kw = dict(iters=K, eps_mode=eps_mode, eps=eps)
+    coop = evc.solve_activations(p["A"], X, H0, **kw)
+    solo = evc.solve_activations(p["A"], X, H0, cooperative=False, **kw)
+    assert_close64(coop, solo, f"coop vs solo N={N} T={T}", rtol=1e-11)
+    assert (coop[5] == 0).all() and (coop[:, 3] == 0).all()
+    if N * T <= 4096 * 100:          # the oracle's Gram product is the slow part
+        code = {"add": o.EPS_ADD, "zero_replace": o.EPS_ZERO_REPLACE}[eps_mode]
+        want = o.mu_solve(p["A"], X, H0, K, eps_mode=code, eps=eps, algo="factored")
+        assert_close64(coop, want, f"coop vs oracle N={N} T={T}")
+
+
+def test_cooperative_launch_with_stop_rule_and_two_utterances():
+    """The default call (_factorize: check every 10 iterations, tol) on the cooperative path: launches of 10
+    iterations, per-utterance freezing between them."""
+    import warnings
+    from exemplars_vc_amd.compat.factorize import factorize_utterances
+    o = oracle()
+    M, N = 25, 4096
+    rows = [np.ascontiguousarray(o.synth_problem(M, N, T, seed=T)["X"].T) for T in (70, 45)]
+    W = np.ascontiguousarray(o.synth_problem(M, N, 8, seed=1)["A"].T)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        Hs, n_iter = factorize_utterances(rows, W, tol=2e-3)
+    for X_rows, H, n in zip(rows, Hs, n_iter):
+        act, n_ref, _ = o.sklearn_mu_fixed_dictionary(X_rows, W, 150, 2e-3)
+        assert int(n) == n_ref
+        assert_close64(H, act.T, "coop + stop rule")
+
+
+@pytest.mark.parametrize("Mb,N,T", [(25, 4096, 688), (1, 17, 3), (16, 100, 16), (33, 130, 50), (64, 257, 31),
+                                    (65, 96, 40), (201, 300, 45)])
+@pytest.mark.parametrize("layout", ["bin_major", "frame_major"])
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_synthesize_alone(Mb, N, T, layout, dt):
+    """evc_synthesize (np.matmul(H.T, B), 04_align_n_nmf.py:391) on caller memory: the skinny kernel
+    (Mb <= 64: wavefronts split the exemplars) and the strided MFMA fallback, both layouts and dtypes,
+    ragged sizes, plus a strided (sliced) activation matrix."""
+    import torch
+    import exemplars_vc_amd as evc
+    rng = np.random.default_rng(Mb * 1000 + N + T)
+    B = rng.random((Mb, N)).astype(dt)
+    Hfull = rng.random((N, T + 5)).astype(dt)
+    H = Hfull[:, :T]
+    want = B.astype(np.float64) @ H.astype(np.float64)
+    tol = 1e-12 if dt == np.float64 else 2e-5
+    if layout == "bin_major":
+        Y = evc.synthesize(B, np.ascontiguousarray(H), layout=layout)
+        assert Y.shape == (Mb, T) and Y.dtype == dt
+        assert np.abs(Y - want).max() <= tol * np.abs(want).max()
+        # a strided view on the device: columns 0..T-1 of a wider matrix (row stride T + 5)
+        Hd = torch.as_tensor(Hfull).cuda()[:, :T]
+        Yd = evc.synthesize(torch.as_tensor(B).cuda(), Hd, layout=layout).cpu().numpy()
+        assert np.abs(Yd - want).max() <= tol * np.abs(want).max()
+    else:
+        Y = evc.synthesize(np.ascontiguousarray(B.T), np.ascontiguousarray(H.T), layout=layout)
+        assert Y.shape == (T, Mb) and Y.dtype == dt
+        assert np.abs(Y.T - want).max() <= tol * np.abs(want).max()

@@ -30,7 +30,8 @@ def run(name, M, N, K, T, algo="factored", l1=0.0, dtype="f64", reps=2, utt=688)
     for r in range(reps + 1):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         evc.solve_activations(A, X, layout="frame_major", iters=K, eps_mode="zero_replace", init="sklearn",
-                              algo=algo, l1=l1, utt_offsets=offs, out=H, loop_events=(e0, e1))
+                              algo=algo, l1=l1, utt_offsets=offs, out=H, loop_events=(e0, e1),
+                              cooperative=not os.environ.get("EVC_NO_COOP"))
         Y = evc.synthesize(B, H, layout="frame_major")
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         if r > 0 and (best is None or dt < best[0]): best = (dt, e0.elapsed_time(e1))
@@ -46,12 +47,19 @@ def run(name, M, N, K, T, algo="factored", l1=0.0, dtype="f64", reps=2, utt=688)
 cases = {
     "C1": lambda: run("C1 M=25 N=512 K=50 (one utterance)", 25, 512, 50, 688),
     "C2_1utt": lambda: run("C2 M=25 N=4096 K=100 one utterance", 25, 4096, 100, 688),
+    "C2_2utt": lambda: run("C2 M=25 N=4096 K=100 two utterances", 25, 4096, 100, 688 * 2),
+    "C5_1utt": lambda: run("C5 M=25 N=16384 K=100 L1 one utterance", 25, 16384, 100, 688, l1=0.25),
+    "N1024_1utt": lambda: run("M=25 N=1024 K=100 one utterance (the per-workgroup share of C2 at 4 cooperating workgroups)", 25, 1024, 100, 688),
     "C2_gram": lambda: run("C2 GRAM algebra, one utterance", 25, 4096, 100, 688, algo="gram"),
     "C2_gram16": lambda: run("C2 GRAM algebra, 16 utterances", 25, 4096, 100, 688 * 16, algo="gram"),
     "C3_1utt": lambda: run("C3 M=513 N=8192 K=200 one utterance", 513, 8192, 200, 688),
     "C3_16k": lambda: run("C3 M=513 N=8192 K=200 T=16384", 513, 8192, 200, 16384, reps=1),
     "C5": lambda: run("C5 M=25 N=16384 K=100 L1 T=16x688", 25, 16384, 100, 688 * 16, l1=0.25),
     "C5_513": lambda: run("C5 M=513 N=16384 K=100 L1 one utterance", 513, 16384, 100, 688, l1=5.13, reps=1),
+    # the reference's own default flow (config use_stft=1): |Re STFT| of a complex64 transform -> float32, M=201
+    "STFT_f32_1utt": lambda: run("STFT M=201 N=4096 K=150 float32 one utterance", 201, 4096, 150, 688, dtype="f32"),
+    "STFT_f32_16": lambda: run("STFT M=201 N=4096 K=150 float32 16 utterances", 201, 4096, 150, 688 * 16, dtype="f32"),
+    "STFT_f64_16": lambda: run("STFT M=201 N=4096 K=150 float64 16 utterances", 201, 4096, 150, 688 * 16),
     "C2_f32": lambda: run("C2 float32 (generic path) 16 utterances", 25, 4096, 100, 688 * 16, dtype="f32"),
 }
 for k in (sys.argv[1:] or list(cases)):
