@@ -82,6 +82,19 @@ def _to_dev(x, tdtype, device):
     return x, was_numpy
 
 
+def _to_host(t):
+    """Device tensor -> numpy.  Large results go through page-locked memory (torch caches the pinned
+    blocks): a pageable download of one utterance's activations (22 MB) costs as much as its solve."""
+    torch = _torch()
+    if t.numel() * t.element_size() < (1 << 20):
+        return t.cpu().numpy()
+    t = t.contiguous()
+    host = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    host.copy_(t, non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return host.numpy()
+
+
 def _ld(x):
     return int(x.stride(0)) if x.shape[0] > 1 else int(max(x.shape[1], 1))
 
@@ -228,10 +241,10 @@ def _solve(A, X, H0, B, *, layout="bin_major", iters=100, eps_mode="add", eps=No
                 ws.data_ptr(), ws.numel(), ni_p, er_p, C.c_void_p(stream))
     _lib.check(st, "evc_nmf_solve" if B is None else "evc_nmf_convert")
     to_np = x_np and out is None
-    H_out = None if H_d is None else (H_d.cpu().numpy() if to_np else H_d)
+    H_out = None if H_d is None else (_to_host(H_d) if to_np else H_d)
     res = [H_out] if B is None else ([H_out] if want_h else [])
     if B is not None:
-        res.append(Y_d.cpu().numpy() if (x_np and out_y is None) else Y_d)
+        res.append(_to_host(Y_d) if (x_np and out_y is None) else Y_d)
     if info:
         res.append({"n_iter": n_iter, "err": err})
     return res[0] if len(res) == 1 else tuple(res)
@@ -263,7 +276,7 @@ def synthesize(B, H, *, layout="bin_major", dtype=None, device=None):
         st = L.evc_synthesize(B_d.data_ptr(), _ld(B_d), H_d.data_ptr(), _ld(H_d), Y.data_ptr(),
                               _ld(Y), Mb, N, T, lay, dcode, C.c_void_p(stream))
     _lib.check(st, "evc_synthesize")
-    return Y.cpu().numpy() if h_np else Y
+    return _to_host(Y) if h_np else Y
 
 
 def frame_residuals(A, X, H, *, layout="bin_major", dtype=None, device=None):

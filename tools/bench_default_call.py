@@ -6,7 +6,8 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import exemplars_vc_amd as evc
 
-U, Tu, M, N = 96, 688, 25, 4096
+U = int(sys.argv[1]) if len(sys.argv) > 1 else 96
+Tu, M, N = 688, 25, 4096
 dev = torch.device("cuda")
 g = torch.Generator(device=dev); g.manual_seed(3)
 A = torch.rand(N, M, generator=g, device=dev, dtype=torch.float64) + 1e-3
@@ -24,6 +25,18 @@ for tol, iters in [(0.0, 150), (1e-4, 150), (1e-3, 150)]:
                                         stop_rule="sklearn" if tol > 0 else "none", tol=tol, info=True)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
     ni = info["n_iter"]
-    print(json.dumps({"tol": tol, "max_iter": iters, "seconds": dt, "frames_per_s": U * Tu / dt,
+    print(json.dumps({"utterances": U, "tol": tol, "max_iter": iters, "seconds": dt, "frames_per_s": U * Tu / dt,
                       "n_iter_min": int(ni.min()), "n_iter_max": int(ni.max()), "n_iter_mean": float(ni.mean()),
                       "frame_iterations_per_s": float(ni.mean()) * U * Tu / dt}))
+
+# the literal drop-in: _factorize(X, W) on numpy arrays, one utterance per call (upload, solve, download)
+import warnings
+from exemplars_vc_amd.compat.factorize import _factorize
+Xn, Wn = X[:Tu].cpu().numpy(), A.cpu().numpy()
+with warnings.catch_warnings():
+    warnings.simplefilter("ignore")
+    for tol in (1e-4, 1e-3):
+        for rep in range(3):
+            t0 = time.perf_counter(); Hn = _factorize(Xn, Wn, tol=tol); dt = time.perf_counter() - t0
+        print(json.dumps({"call": "_factorize(X[688x25], W[4096x25]) numpy in/out", "tol": tol, "seconds": dt,
+                          "frames_per_s": Tu / dt}))
