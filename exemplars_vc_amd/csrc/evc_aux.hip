@@ -306,6 +306,27 @@ hipError_t utt_check(const double* err2, const UttState& u, int n_utt, int c, in
     return hipGetLastError();
 }
 
+// element-type conversion of a row-major matrix (rows x cols, leading dimensions in elements)
+template <typename S, typename D>
+__global__ __launch_bounds__(256) void k_cvt2d(const S* __restrict__ src, long lds_, long rows, long cols,
+                                               D* __restrict__ dst, long ldd) {
+    const long n = rows * cols;
+    for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < n; g += (long)gridDim.x * 256) {
+        const long r = g / cols, c = g % cols;
+        dst[r * ldd + c] = (D)src[r * lds_ + c];
+    }
+}
+template <typename S, typename D>
+hipError_t cvt2d(const S* src, long lds_, long rows, long cols, D* dst, long ldd, hipStream_t s) {
+    if (rows <= 0 || cols <= 0) return hipSuccess;
+    const long n = rows * cols;
+    const unsigned grid = (unsigned)((n + 255) / 256 < 65536 ? (n + 255) / 256 : 65536);
+    hipLaunchKernelGGL((k_cvt2d<S, D>), dim3(grid), dim3(256), 0, s, src, lds_, rows, cols, dst, ldd);
+    return hipGetLastError();
+}
+template hipError_t cvt2d<float, double>(const float*, long, long, long, double*, long, hipStream_t);
+template hipError_t cvt2d<double, float>(const double*, long, long, long, float*, long, hipStream_t);
+
 #define EVC_INST(T)                                                                                 \
     template hipError_t copy2d<T>(const T*, long, int, int, int, T*, long, int, int, int, hipStream_t); \
     template hipError_t utt_sklearn_h0<T>(const T*, int, int, int, const UttState&, int, hipStream_t); \

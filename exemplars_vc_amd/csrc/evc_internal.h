@@ -104,6 +104,9 @@ hipError_t synth_skinny(const T* H, long hst, long hsn, const T* B, long bsn, lo
 // dst (dst_rows x dst_cols, row stride dst_ld) = src (src_rows x src_cols), zero outside src.
 // src_trans: element (r,c) of the logical matrix is src[c*src_ld + r] instead of src[r*src_ld + c];
 // dst_trans likewise for the destination.
+// element-type conversion of a row-major matrix (the float32 surfaces ride the float64 fused path)
+template <typename S, typename D>
+hipError_t cvt2d(const S* src, long lds_, long rows, long cols, D* dst, long ldd, hipStream_t s);
 template <typename T>
 hipError_t copy2d(const T* src, long src_ld, int src_rows, int src_cols, int src_trans, T* dst,
                   long dst_ld, int dst_rows, int dst_cols, int dst_trans, hipStream_t s);

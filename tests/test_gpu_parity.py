@@ -595,3 +595,38 @@ def test_synthesize_alone(Mb, N, T, layout, dt):
         Y = evc.synthesize(np.ascontiguousarray(B.T), np.ascontiguousarray(H.T), layout=layout)
         assert Y.shape == (T, Mb) and Y.dtype == dt
         assert np.abs(Y.T - want).max() <= tol * np.abs(want).max()
+
+
+@pytest.mark.parametrize("N", [130, 1024])
+@pytest.mark.parametrize("eps_mode,eps", [("add", 1e-9), ("none", 0.0), ("zero_replace", 1.1920929e-7)])
+@pytest.mark.parametrize("layout", ["bin_major", "frame_major"])
+def test_float32_small_bin_count_rides_the_float64_kernels(N, eps_mode, eps, layout):
+    """float32 callers with M <= 32 are widened, solved by the float64 fused kernels and narrowed on the
+    way out: the result is the float64 solution of the float32 inputs, rounded once (6e-8), for H and Y,
+    in both layouts, with a given start; the float32 generic path (fused=False) stays available and agrees
+    to float32 accuracy."""
+    import exemplars_vc_amd as evc
+    o = oracle()
+    M, Mb, T, K = 25, 20, 70, 40
+    p = o.synth_problem(M, N, T, Mb=Mb, seed=N)
+    A, X, B = (p[k].astype(np.float32) for k in ("A", "X", "B"))
+    H0 = (np.random.default_rng(N).random((N, T)) + 1e-4).astype(np.float32)
+    code = {"add": o.EPS_ADD, "none": o.EPS_NONE, "zero_replace": o.EPS_ZERO_REPLACE}[eps_mode]
+    want = o.mu_solve(A.astype(np.float64), X.astype(np.float64), H0.astype(np.float64), K, eps_mode=code, eps=eps)
+    want_y = B.astype(np.float64) @ want
+    tr = (lambda a: a) if layout == "bin_major" else (lambda a: np.ascontiguousarray(a.T))
+    H, Y = evc.convert(tr(A), tr(X), tr(B), tr(H0), layout=layout, iters=K, eps_mode=eps_mode, eps=eps)
+    assert H.dtype == np.float32 and Y.dtype == np.float32
+    H, Y = (H, Y) if layout == "bin_major" else (H.T, Y.T)
+    np.testing.assert_allclose(H, want, rtol=2e-7, atol=1e-30)
+    np.testing.assert_allclose(Y, want_y, rtol=2e-7)
+    Hg = evc.solve_activations(tr(A), tr(X), tr(H0), layout=layout, iters=K, eps_mode=eps_mode, eps=eps, fused=False)
+    Hg = Hg if layout == "bin_major" else Hg.T
+    assert Hg.dtype == np.float32
+    np.testing.assert_allclose(Hg, want, rtol=5e-3, atol=1e-5 * float(want.max()))
+    # sklearn initialisation and the per-utterance stop rule travel through the widened call as well
+    Hs, info = evc.solve_activations(tr(A), tr(X), layout=layout, iters=60, eps_mode="zero_replace", init="sklearn",
+                                     check_every=10, stop_rule="sklearn", tol=1e-3, info=True)
+    act, n_ref, _ = o.sklearn_mu_fixed_dictionary(X.T.astype(np.float64), A.T.astype(np.float64), 60, 1e-3)
+    assert int(info["n_iter"][0]) == n_ref
+    np.testing.assert_allclose(Hs if layout == "bin_major" else Hs.T, act.T, rtol=2e-7, atol=1e-30)
