@@ -220,15 +220,17 @@ def main():
         loop_s = float(np.mean(loop_ms)) / 1e3
         fl_loop = loop_flops_per_frame(M, N, K, args.algo) * T
         achieved = fl_loop / loop_s / 1e12
-        peak = PEAK_F64_TFLOPS if args.dtype == "f64" else PEAK_F32_TFLOPS
-        fused = args.algo == "factored" and args.dtype == "f64" and M <= 32 and not args.no_fused
+        fused = args.algo == "factored" and M <= 32 and not args.no_fused
+        # float32 callers with M <= 32 are widened onto the float64 fused kernels: the arithmetic type is f64
+        arith = "f64" if (args.dtype == "f64" or fused) else "f32"
+        peak = PEAK_F64_TFLOPS if arith == "f64" else PEAK_F32_TFLOPS
         # HBM bytes per launch from the committed PMC passes of this very workload (rocprofv3 cannot
         # run inside the timed process); null when the profile on file is for another workload
         traffic = None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_bench_c2.json")))
             wl = pm["workload"]
-            if fused and (wl["M"], wl["N"], wl["K"], wl["frames"], wl["dtype"]) == (M, N, K, T, args.dtype):
+            if fused and (wl["M"], wl["N"], wl["K"], wl["frames"], wl["dtype"]) == (M, N, K, T, args.dtype):  # noqa: E501
                 traffic = pm["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
@@ -237,13 +239,13 @@ def main():
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
+            "dtype": arith, "data": "synthetic",
             "config": {"workload": f"C2 (BASELINE configs[1]): SF1->TF1-shaped dictionary, M={M} bins, "
                                    f"N={N} exemplars, K={K} MU iterations, {U} utterances x {Tu} frames "
                                    f"= {T} frames per GPU per step, solve + synthesis B*H",
                        "algo": args.algo, "kernel": "k_fused_res (persistent, register-resident, 1 launch per step)" if fused
                        else "k_gemm_nt(+mu epilogue), launches per iteration",
-                       "frames_per_gpu": T, "parallelism": f"utterance shards x{world}"},
+                       "frames_per_gpu": T, "parallelism": f"utterance shards x{world}", "io_dtype": args.dtype},
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak, "traffic": traffic,
