@@ -189,7 +189,8 @@ int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_sol
         fb.coop_c = fused_res_coop_factor(w.fl.NT, w.fl.TT, cus);
     }
     int* coop_abort = fb.coop_cnt + COOP_MAX_TILES;
-    if (fb.coop_c > 1) HIP_TRY(hipMemsetAsync(coop_abort, 0, sizeof(int), s));
+    // reserved bit 3 (tests): start with the abort flag raised, so that the call takes the retry path below
+    if (fb.coop_c > 1) HIP_TRY(hipMemsetAsync(coop_abort, (o.reserved & 8) ? 1 : 0, sizeof(int), s));
     int first = 1;
     if (o.check_every > 0 && o.stop_rule == EVC_STOP_SKLEARN) {   // error_at_init
         HIP_TRY(fused_iterate(w.fl, fb, w.u, d.N, d.T_, 0, 1, 1, w.err2, o.eps_mode, o.eps, o.l1,
@@ -281,11 +282,23 @@ int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int 
     else if (o.init_mode == EVC_INIT_CONST) HIP_TRY(utt_const_h0(w.u, n_utt, o.init_value, s));
 
     if (fused) {     // activations live in the packed tile layout from start to finish
-        if (o.init_mode == EVC_INIT_GIVEN)
-            HIP_TRY(fused_import_h(w.fl, w.fb.Hp, reinterpret_cast<const double*>(H), ldh, fm ? 1 : 0, T_, N, s));
-        else
-            HIP_TRY(fused_fill_h(w.fl, w.fb.Hp, N, T_, w.u, s));
-        int st = solve_fused(w, d, o, n_utt, s);
+        evc_solve_opts oo = o;
+        int st = ST_OK;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            if (o.init_mode == EVC_INIT_GIVEN)
+                HIP_TRY(fused_import_h(w.fl, w.fb.Hp, reinterpret_cast<const double*>(H), ldh, fm ? 1 : 0, T_, N, s));
+            else
+                HIP_TRY(fused_fill_h(w.fl, w.fb.Hp, N, T_, w.u, s));
+            st = solve_fused(w, d, oo, n_utt, s);
+            if (st != ST_COOP_TIMEOUT) break;
+            // A cooperative launch gave up waiting for a peer workgroup (another process or stream held the
+            // CUs it needed): nothing has left the workspace yet - the caller's H still holds its start
+            // values - so the solve is simply redone with one workgroup per frame tile.
+            oo.reserved |= 4;
+            HIP_TRY(utt_setup(w.u, n_utt, T_, d.Tp, o.iters, s));
+            if (o.init_mode == EVC_INIT_SKLEARN) HIP_TRY(utt_sklearn_h0<T>(w.Xt, d.Mk, M, N, w.u, n_utt, s));
+            else if (o.init_mode == EVC_INIT_CONST) HIP_TRY(utt_const_h0(w.u, n_utt, o.init_value, s));
+        }
         if (st) return st;
         st = finish_fused<T>(w, d, o, H, ldh, y, s);
         if (st) return st;

@@ -51,8 +51,9 @@ constexpr int RNW = 8;    // wavefronts per workgroup
 // iteration parity: a member writes iteration i+2 only after it has read every peer's word of iteration i+1,
 // which the peer wrote after reading this member's word of iteration i.  The host launches TT*c <= #CUs
 // workgroups of one-per-CU size, so all members are resident; a poll budget bounds every wait, and a
-// workgroup that exhausts it raises coop_abort, on which all leave (no hang; the host reports the launch void).
-constexpr unsigned COOP_POLL_LIMIT = 1u << 22;
+// workgroup that exhausts it raises coop_abort, on which all leave (no hang); the host then redoes the solve
+// with one workgroup per tile (two processes sharing a GPU can starve each other's members of CUs).
+constexpr unsigned COOP_POLL_LIMIT = 1u << 18;     // a fraction of a second; a peer's sweep takes microseconds
 
 template <int MSTEPS, int RES, int PL, bool KL, bool COOP = false>
 __global__ __launch_bounds__(RNW * 64) void k_fused_res(FusedArgs a) {

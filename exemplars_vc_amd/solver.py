@@ -146,7 +146,7 @@ def _solve(A, X, H0, B, *, layout="bin_major", iters=100, eps_mode="add", eps=No
            stop_rule="none", tol=0.0, utt_offsets: Optional[Sequence[int]] = None,
            dtype=None, device=None, info=False, out=None, loop_events=None,
            fused=True, fused_c=0, want_h=True, out_y=None, loss="frobenius", exact_div=False,
-           cooperative=True):
+           cooperative=True, _fake_coop_timeout=False):
     torch = _torch()
     device = require_device(device)
     L = _lib.lib()
@@ -214,7 +214,7 @@ def _solve(A, X, H0, B, *, layout="bin_major", iters=100, eps_mode="add", eps=No
     # bit 2 disables the cooperative launch used for one or two utterances; bits 8..15 = 1 or 2 force the
     # general streamed kernel with that many frame tiles per workgroup (0 = automatic)
     opts.reserved = ((0 if fused else 1) | (2 if exact_div else 0) | (0 if cooperative else 4)
-                     | ((int(fused_c) & 0xff) << 8))
+                     | (8 if _fake_coop_timeout else 0) | ((int(fused_c) & 0xff) << 8))
     if loop_events is not None:     # (torch.cuda.Event, torch.cuda.Event), already created
         opts.ev_loop_start = int(loop_events[0].cuda_event)
         opts.ev_loop_stop = int(loop_events[1].cuda_event)

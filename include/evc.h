@@ -101,7 +101,7 @@ typedef struct evc_solve_opts {
     int check_every;   /* 0: never evaluate the residual; k>0: every k iterations */
     int stop_rule;     /* EVC_STOP_* */
     int reserved;      /* 0; knobs: bit 0 = no fused kernels, bit 1 = correctly rounded quotients in the
-                          fused kernels (always on with EVC_STOP_PYMF), bit 2 = no cooperative launch,
+                          fused kernels (always on with EVC_STOP_PYMF), bit 2 = no cooperative launch, bit 3 = (tests) pretend the cooperative launch timed out,
                           bits 8..15 = 1|2 general kernel */
     int loss;          /* EVC_LOSS_* */
     int reserved2;     /* 0 */

@@ -630,3 +630,49 @@ def test_float32_small_bin_count_rides_the_float64_kernels(N, eps_mode, eps, lay
     act, n_ref, _ = o.sklearn_mu_fixed_dictionary(X.T.astype(np.float64), A.T.astype(np.float64), 60, 1e-3)
     assert int(info["n_iter"][0]) == n_ref
     np.testing.assert_allclose(Hs if layout == "bin_major" else Hs.T, act.T, rtol=2e-7, atol=1e-30)
+
+
+def test_cooperative_timeout_falls_back_to_one_workgroup_per_tile():
+    """A cooperative launch whose wait budget ran out (another process holding the CUs its peers needed)
+    voids its results; the solve is then redone non-cooperatively from the untouched inputs.  The flag is
+    raised artificially here: same H, n_iter and error trace as a call that never was cooperative."""
+    import exemplars_vc_amd as evc
+    o = oracle()
+    p = o.synth_problem(25, 4096, 90, seed=5)
+    H0 = np.random.default_rng(5).random((4096, 90)) + 1e-4
+    for kw in (dict(H0=H0, iters=30, eps_mode="add"),
+               dict(H0=None, iters=40, eps_mode="zero_replace", init="sklearn", check_every=10, stop_rule="sklearn",
+                    tol=1e-3, utt_offsets=[0, 50, 90])):
+        h0 = kw.pop("H0")
+        want, iw = evc.solve_activations(p["A"], p["X"], h0, cooperative=False, info=True, **kw)
+        got, ig = evc.solve_activations(p["A"], p["X"], h0, _fake_coop_timeout=True, info=True, **kw)
+        assert np.array_equal(got, want)
+        assert np.array_equal(ig["n_iter"], iw["n_iter"])
+        assert np.array_equal(np.nan_to_num(ig["err"]), np.nan_to_num(iw["err"]))
+
+
+def test_two_processes_sharing_the_gpu_with_cooperative_launches(tmp_path):
+    """Two processes issuing cooperative launches at the same time can starve each other's workgroups of
+    CUs; every wait is bounded and a timed-out solve is redone non-cooperatively, so both must finish with
+    correct results (whether or not a timeout actually occurs in this run)."""
+    import subprocess
+    import sys
+    script = tmp_path / "worker.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))})\n"
+        "import exemplars_vc_amd as evc\n"
+        "from oracle import evc_oracle as o\n"
+        "p = o.synth_problem(25, 4096, 688, seed=int(sys.argv[1]))\n"
+        "want = evc.solve_activations(p['A'], p['X'], iters=20, eps_mode='zero_replace', init='sklearn', cooperative=False)\n"
+        "worst = 0.0\n"
+        "for i in range(60):\n"
+        "    got = evc.solve_activations(p['A'], p['X'], iters=20, eps_mode='zero_replace', init='sklearn')\n"
+        "    worst = max(worst, float(np.abs(got - want).max() / np.abs(want).max()))\n"
+        "print('WORST', worst)\n"
+        "assert worst < 1e-10, worst\n")
+    procs = [subprocess.Popen([sys.executable, str(script), str(k)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for k in (1, 2)]
+    outs = [pr.communicate(timeout=600)[0].decode() for pr in procs]
+    for pr, out in zip(procs, outs):
+        assert pr.returncode == 0 and "WORST" in out, out[-2000:]
