@@ -160,12 +160,21 @@ int synth_rows(const T* Hc, long ldc, const SynthArgs& y, int N, int T_, bool fm
 // The fused persistent path (float64, M <= 32): one launch per `check_every` iterations (or a
 // single launch when no residual is requested); V is carried between launches.
 template <typename T>
-int solve_fused(const Workspace<T>& w, const Dims& d, const evc_solve_opts& o, int n_utt, hipStream_t s) {
+int solve_fused(const Workspace<T>& w, const Dims& d, const evc_solve_opts& o, int n_utt, hipStream_t s,
+                int* coop_used) {
     return ST_UNSUPPORTED;
+}
+// one host round trip: did a cooperative launch of this call give up waiting for a peer workgroup?
+template <typename T>
+int coop_timed_out(const Workspace<T>& w, hipStream_t s, int* aborted) {
+    *aborted = 0;
+    HIP_TRY(hipMemcpyAsync(aborted, w.fb.coop_cnt + COOP_MAX_TILES, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return ST_OK;
 }
 template <>
 int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_solve_opts& o, int n_utt,
-                        hipStream_t s) {
+                        hipStream_t s, int* coop_used) {
     const int c_override = (o.reserved >> 8) & 0xff;     // 0 = automatic, 1 / 2 = general kernel
     // pymf's stop rule compares successive errors against 2.2e-16: it only fires at the reference's
     // iteration if the update reaches the same floating-point fixed point, i.e. with correctly rounded
@@ -213,12 +222,7 @@ int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_sol
                               o.tol, s));
     }
     if (o.ev_loop_stop) HIP_TRY(hipEventRecord((hipEvent_t)o.ev_loop_stop, s));
-    if (fb.coop_c > 1) {        // a cooperative launch that gave up waiting leaves void results: report it
-        int aborted = 0;
-        HIP_TRY(hipMemcpyAsync(&aborted, coop_abort, sizeof(int), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
-        if (aborted) return ST_COOP_TIMEOUT;
-    }
+    *coop_used = fb.coop_c > 1 ? 1 : 0;     // the caller checks the abort flag (one host round trip)
     return ST_OK;
 }
 
@@ -283,25 +287,39 @@ int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int 
 
     if (fused) {     // activations live in the packed tile layout from start to finish
         evc_solve_opts oo = o;
-        int st = ST_OK;
+        // A cooperative launch that gave up waiting for a peer workgroup (another process or stream held the
+        // CUs it needed) leaves void results, and the solve is redone with one workgroup per frame tile.  The
+        // flag costs a host round trip: when the start values can be regenerated it is read after the results
+        // have been exported (they are exported again by the redo); with caller-given start values it is read
+        // before anything is written to the caller's H.
+        const bool check_first = (o.init_mode == EVC_INIT_GIVEN);
         for (int attempt = 0; attempt < 2; ++attempt) {
             if (o.init_mode == EVC_INIT_GIVEN)
                 HIP_TRY(fused_import_h(w.fl, w.fb.Hp, reinterpret_cast<const double*>(H), ldh, fm ? 1 : 0, T_, N, s));
             else
                 HIP_TRY(fused_fill_h(w.fl, w.fb.Hp, N, T_, w.u, s));
-            st = solve_fused(w, d, oo, n_utt, s);
-            if (st != ST_COOP_TIMEOUT) break;
-            // A cooperative launch gave up waiting for a peer workgroup (another process or stream held the
-            // CUs it needed): nothing has left the workspace yet - the caller's H still holds its start
-            // values - so the solve is simply redone with one workgroup per frame tile.
+            int coop_used = 0, aborted = 0;
+            int st = solve_fused(w, d, oo, n_utt, s, &coop_used);
+            if (st) return st;
+            if (coop_used && check_first) {
+                st = coop_timed_out(w, s, &aborted);
+                if (st) return st;
+            }
+            if (!aborted) {
+                st = finish_fused<T>(w, d, o, H, ldh, y, s);
+                if (st) return st;
+                if (coop_used && !check_first) {
+                    st = coop_timed_out(w, s, &aborted);
+                    if (st) return st;
+                }
+            }
+            if (!aborted) break;
+            if (attempt == 1) return ST_COOP_TIMEOUT;      // cannot happen: the redo is not cooperative
             oo.reserved |= 4;
             HIP_TRY(utt_setup(w.u, n_utt, T_, d.Tp, o.iters, s));
             if (o.init_mode == EVC_INIT_SKLEARN) HIP_TRY(utt_sklearn_h0<T>(w.Xt, d.Mk, M, N, w.u, n_utt, s));
             else if (o.init_mode == EVC_INIT_CONST) HIP_TRY(utt_const_h0(w.u, n_utt, o.init_value, s));
         }
-        if (st) return st;
-        st = finish_fused<T>(w, d, o, H, ldh, y, s);
-        if (st) return st;
         return copy_back(w.u, n_utt, n_slots, n_iter_out, err_out, s);
     }
 

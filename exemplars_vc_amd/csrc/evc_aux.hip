@@ -113,26 +113,38 @@ __device__ __forceinline__ double block_sum_256(double v, double* red) {
 
 // h0[u] = sqrt(mean(X_u) / N)   (sklearn _nmf.py:1228-1231); one block per utterance
 template <typename T>
-__global__ __launch_bounds__(256) void k_utt_sklearn_h0(const T* __restrict__ Xt, int ldx, int M,
-                                                        int N, UttState u) {
-    __shared__ double red[4];
+__global__ __launch_bounds__(1024) void k_utt_sklearn_h0(const T* __restrict__ Xt, int ldx, int M,
+                                                         int N, UttState u) {
+    // one block of 16 wavefronts per utterance; every thread keeps 4 independent partial sums (a lone
+    // utterance is a latency problem: 17 200 values), combined in a fixed order
+    __shared__ double red[16];
     const int id = blockIdx.x;
     const long t0 = u.offsets[id], t1 = u.offsets[id + 1];
     const long cnt = (t1 - t0) * M;
-    double acc = 0.0;
-    for (long e = threadIdx.x; e < cnt; e += 256) {
-        const long t = t0 + e / M;
-        const int m = (int)(e % M);
-        acc += (double)Xt[t * ldx + m];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (long e0 = threadIdx.x; e0 < cnt; e0 += 4096) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const long e = e0 + 1024L * v;
+            if (e < cnt) acc[v] += (double)Xt[(t0 + e / M) * ldx + (int)(e % M)];
+        }
     }
-    const double tot = block_sum_256(acc, red);
-    if (threadIdx.x == 0) u.h0[id] = cnt > 0 ? sqrt(tot / (double)cnt / (double)N) : 0.0;
+    double a = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < 16; ++w) tot += red[w];
+        u.h0[id] = cnt > 0 ? sqrt(tot / (double)cnt / (double)N) : 0.0;
+    }
 }
 
 template <typename T>
 hipError_t utt_sklearn_h0(const T* Xt, int ldx, int M, int N, const UttState& u, int n_utt,
                           hipStream_t s) {
-    hipLaunchKernelGGL((k_utt_sklearn_h0<T>), dim3(n_utt), dim3(256), 0, s, Xt, ldx, M, N, u);
+    hipLaunchKernelGGL((k_utt_sklearn_h0<T>), dim3(n_utt), dim3(1024), 0, s, Xt, ldx, M, N, u);
     return hipGetLastError();
 }
 

@@ -287,8 +287,8 @@ hipError_t gemm_strided(const T* L, long lsi, long lsk, const T* R, long rsj, lo
 // ------------------------------------------------------------------------------------------
 // synthesis Y = B H for a handful of bins (Mb <= 64) and a long contraction (N exemplars): tall and
 // skinny, bound by the single pass over H.  One workgroup per 16 frames; its 8 wavefronts split N, each
-// accumulating 16 x 16 output tiles straight from global memory (a lane reads 4 consecutive exemplars
-// of its frame, which feed 4 MFMA k-steps), then a fixed-order LDS reduction.  Caller strides.
+// accumulating 16 x 16 output tiles straight from global memory, then a fixed-order LDS reduction.
+// Caller strides.
 //   H(t, n) = H[t hst + n hsn],  B(n, mb) = B[n bsn + mb bsm],  Y(t, mb) = Y[t yst + mb ysm]
 // ------------------------------------------------------------------------------------------
 constexpr int SYN_WAVES = 8;
@@ -311,23 +311,38 @@ __global__ __launch_bounds__(SYN_WAVES * 64) void k_synth_skinny(const T* __rest
     const int per = (tiles + SYN_WAVES - 1) / SYN_WAVES;
     const int j1 = min(tiles, (w + 1) * per);
     const bool t_ok = t < T_;
-    for (int j = w * per; j < j1; ++j) {
-        const long n0 = 16L * j + 4 * q;              // this lane's 4 exemplars: n0 .. n0+3 <-> k-steps 0..3
-        T hv[4], bv[MT][4];
+    // four exemplar tiles per round: their loads are all issued before the first MFMA (the kernel is a single
+    // pass over H, so the only thing to hide is load latency)
+    constexpr int UNR = 4;
+    for (int j = w * per; j < j1; j += UNR) {
+        T hv[UNR][4], bv[UNR][MT][4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const bool n_ok = n0 + s < N;
-            hv[s] = (t_ok && n_ok) ? H[t * hst + (n0 + s) * hsn] : T(0);
+        for (int v = 0; v < UNR; ++v) {
+            const long n0 = 16L * (j + v) + q;        // k-step s <-> exemplar n0 + 4 s (the 4 lane groups of a
+                                                      // row read 4 consecutive exemplars per instruction)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                const int mb = 16 * m + i16;
-                bv[m][s] = (n_ok && mb < Mb) ? B[(n0 + s) * bsn + mb * bsm] : T(0);
+            for (int s = 0; s < 4; ++s) {
+                const long n = n0 + 4 * s;
+                const bool n_ok = (j + v < j1) && (n < N);
+                // out-of-range lanes read element 0 and discard it: an unconditional load keeps the round's
+                // loads in flight together (a predicated one becomes a branch with its own wait)
+                const T hval = H[(t_ok && n_ok) ? t * hst + n * hsn : 0];
+                hv[v][s] = (t_ok && n_ok) ? hval : T(0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const int mb = 16 * m + i16;
+                    const bool ok = n_ok && mb < Mb;
+                    const T bval = B[ok ? n * bsn + mb * bsm : 0];
+                    bv[v][m][s] = ok ? bval : T(0);
+                }
             }
         }
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int v = 0; v < UNR; ++v)
 #pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = Mma<T>::mma(hv[s], bv[m][s], acc[m]);
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m] = Mma<T>::mma(hv[v][s], bv[v][m][s], acc[m]);
     }
 #pragma unroll
     for (int m = 0; m < MT; ++m)
