@@ -23,9 +23,12 @@
  *   Math (BASELINE.json north_star): X is M x T (bins x frames), A is M x N (source
  *   exemplar dictionary), B is Mb x N (parallel target dictionary), H is N x T, Y = B H.
  *   All pointers are DEVICE pointers unless marked "host".  Nothing here allocates,
- *   frees or throws; every function returns a status (0 ok, <0 invalid argument,
- *   >0 a hipError_t value).  Work is enqueued on `stream`; the only host synchronisation
- *   is the one needed to hand back n_iter/err when those host pointers are non-NULL.
+ *   frees or throws; every function returns a status (0 ok; -1 invalid argument, -2 workspace
+ *   too small, -3 unsupported combination, -4 cooperative launch timed out twice (not reachable:
+ *   the redo is not cooperative); >0 a hipError_t value).  Work is enqueued on `stream`; the host
+ *   synchronises only to hand back n_iter/err when those host pointers are non-NULL, and once per
+ *   call that took the cooperative launch (a few frame tiles: one or two utterances), to learn
+ *   whether it has to be redone.
  *   No global mutable state: calls on distinct streams/devices are independent and the
  *   caller's current device (hipSetDevice) is honoured.
  */
