@@ -271,11 +271,31 @@ def main():
                                  layout="frame_major", iters=K, eps_mode="zero_replace", init="sklearn",
                                  algo=args.algo, dtype=args.dtype, fused=not args.no_fused)
             nz = act_cpu != 0
+            # a lone utterance takes the cooperative launch; the timed batch runs one workgroup per frame
+            # tile: check that variant of the kernel on the same sample too
+            Hb = evc.solve_activations(np.ascontiguousarray(p["A"].T), Xs, layout="frame_major", iters=K,
+                                       eps_mode="zero_replace", init="sklearn", algo=args.algo, dtype=args.dtype,
+                                       fused=not args.no_fused, cooperative=False)
             res["parity"] = {
                 "H_max_rel_err": float(np.max(np.abs(Hg[nz] - act_cpu[nz]) / act_cpu[nz])),
+                "H_max_rel_err_batch_kernel": float(np.max(np.abs(Hb[nz] - act_cpu[nz]) / act_cpu[nz])),
                 "Y_max_rel_err": float(np.max(np.abs(Yg - Y_cpu) / np.abs(Y_cpu))),
                 "rtol_required": 1e-4,
             }
+            # latency of ONE utterance (device-resident inputs, solve + synthesis): the reference's call pattern
+            n1 = args.cpu_frames
+            X1, H1, Y1 = X[:n1], H[:n1], Yout[:n1]
+            l0, l1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for rep in range(13):
+                if rep == 3:
+                    l0.record()
+                evc.convert(A, X1, B, layout="frame_major", iters=K, eps_mode="zero_replace", init="sklearn",
+                            algo=args.algo, out=H1, out_y=Y1, fused=not args.no_fused, loss=args.loss)
+            l1.record()
+            torch.cuda.synchronize()
+            ms1 = l0.elapsed_time(l1) / 10.0
+            res["one_utterance"] = {"frames": n1, "ms": ms1, "frames_per_s": n1 / ms1 * 1e3,
+                                    "note": "cooperative launch: several workgroups per 16-frame tile"}
         print(json.dumps(res))
     if world > 1:
         dist.barrier()
