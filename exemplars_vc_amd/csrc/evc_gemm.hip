@@ -183,9 +183,13 @@ hipError_t gemm_nt(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int 
         int splits = 1;
         const long slab = (long)I * ldc;
         if (scratch && ldc == J) {
-            while (splits < 8 && blocks * splits * 2 <= 512 && (Kd / (splits * 2)) % KS == 0 && Kd / (splits * 2) >= 512 &&
-                   (size_t)(splits * 2) * slab <= scratch_elems)
-                splits *= 2;
+            // the largest split (<= 8) that divides the k-slabs evenly, keeps <= 512 workgroups and leaves every
+            // workgroup a worthwhile chunk (512 deep for long contractions, 64 for short ones such as the
+            // 400-point DFTs of Griffin-Lim, whose 84 tiles would otherwise run 25 slabs each on a third of the CUs)
+            const int nslabs = Kd / KS, chunk = Kd >= 1024 ? 512 : 64;
+            for (int sp = 2; sp <= 8; ++sp)
+                if (nslabs % sp == 0 && blocks * sp <= 512 && Kd / sp >= chunk && (size_t)sp * slab <= scratch_elems)
+                    splits = sp;
         }
         if (splits == 1) return launch_nt<T, 64, 64, 32, 32, false>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s);
         hipError_t e = launch_nt<T, 64, 64, 32, 32, false>(L, ldl, R, ldr, scratch, ldc, I, J, Kd, ep, s, splits, slab);

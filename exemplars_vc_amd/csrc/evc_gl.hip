@@ -126,8 +126,9 @@ size_t gl_workspace_bytes(int T_, int F, int hop, int iters) {
     const GlDims d = gl_dims(T_, F, hop);
     size_t n = (size_t)d.J1 * d.K1 + (size_t)d.J2 * d.K2       // tables
              + (size_t)d.Tp * d.J1 + (size_t)d.Tp * d.K2 + (size_t)d.Tp * d.J2   // S, P, Fr
-             + 2 * (size_t)d.Lp + (size_t)(iters > 0 ? iters : 1);                // x ping-pong, rmse trace
-    return n * sizeof(double) + 8 * 256;
+             + 2 * (size_t)d.Lp + (size_t)(iters > 0 ? iters : 1)                 // x ping-pong, rmse trace
+             + 8 * (size_t)d.Tp * (d.J1 > d.J2 ? d.J1 : d.J2);                    // split-K slabs of the contractions
+    return n * sizeof(double) + 10 * 256;
 }
 
 // x: in = initial signal (the reference draws randn), out = reconstruction; length T*hop + F.
@@ -145,6 +146,8 @@ hipError_t gl_run(const double* mag, long ldm, int T_, int F, int hop, int iters
     double* xa = take((size_t)d.Lp);
     double* xb = take((size_t)d.Lp);
     double* tr = take((size_t)(iters > 0 ? iters : 1));
+    const size_t nsplit = 8 * (size_t)d.Tp * (d.J1 > d.J2 ? d.J1 : d.J2);
+    double* split = take(nsplit);
 
     const long nt = (long)d.J1 * d.K1 + (long)d.J2 * d.K2;
     hipLaunchKernelGGL(k_gl_tables, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, d, Wf, Wi, false);
@@ -155,11 +158,11 @@ hipError_t gl_run(const double* mag, long ldm, int T_, int F, int hop, int iters
     double* xn = xb;
     for (int it = 0; it < iters; ++it) {
         // S[t][:] = x[hop t : hop t + F] W_f     (rows of L overlap: row stride = hop)
-        e = gemm_nt<double>(xc, hop, Wf, d.K1, S, d.J1, d.Tp, d.J1, d.K1, s);
+        e = gemm_nt<double>(xc, hop, Wf, d.K1, S, d.J1, d.Tp, d.J1, d.K1, s, split, nsplit);
         if (e != hipSuccess) return e;
         const long np_ = (long)d.Tp * d.K2;
         hipLaunchKernelGGL(k_gl_project, dim3((unsigned)((np_ + 255) / 256)), dim3(256), 0, s, S, d.J1, mag, ldm, d, P);
-        e = gemm_nt<double>(P, d.K2, Wi, d.K2, Fr, d.J2, d.Tp, d.J2, d.K2, s);
+        e = gemm_nt<double>(P, d.K2, Wi, d.K2, Fr, d.J2, d.Tp, d.J2, d.K2, s, split, nsplit);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_gl_overlap_add, dim3((unsigned)((d.Lp + 255) / 256)), dim3(256), 0, s, Fr, d.J2, d, xn);
         if (rmse_host) hipLaunchKernelGGL(k_gl_rmse, dim3(1), dim3(256), 0, s, xn, xc, d.L, tr + it);
