@@ -172,7 +172,8 @@ __global__ __launch_bounds__(256) void k_sum_slabs(const T* __restrict__ part, l
 
 template <typename T>
 hipError_t gemm_nt(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int I, int J, int Kd,
-                   hipStream_t s, T* scratch, size_t scratch_elems) {
+                   hipStream_t s, T* scratch, size_t scratch_elems, int* splits_out) {
+    if (splits_out) *splits_out = 0;
     if (I <= 0 || J <= 0) return hipSuccess;
     if (I % 128 || J % 64 || Kd % KS || Kd <= 0) return hipErrorInvalidValue;
     MuEpilogue<T> ep{};
@@ -194,6 +195,10 @@ hipError_t gemm_nt(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int 
         if (splits == 1) return launch_nt<T, 64, 64, 32, 32, false>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s);
         hipError_t e = launch_nt<T, 64, 64, 32, 32, false>(L, ldl, R, ldr, scratch, ldc, I, J, Kd, ep, s, splits, slab);
         if (e != hipSuccess) return e;
+        if (splits_out) {      // the caller's next kernel sums the slabs itself (scratch + z * I * ldc, z < splits)
+            *splits_out = splits;
+            return hipSuccess;
+        }
         hipLaunchKernelGGL((k_sum_slabs<T>), dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, s, scratch, slab, splits,
                            slab, C);
         return hipGetLastError();
@@ -380,7 +385,7 @@ hipError_t synth_skinny(const T* H, long hst, long hsn, const T* B, long bsn, lo
 }
 
 #define EVC_INST(T)                                                                                  \
-    template hipError_t gemm_nt<T>(const T*, int, const T*, int, T*, int, int, int, int, hipStream_t, T*, size_t); \
+    template hipError_t gemm_nt<T>(const T*, int, const T*, int, T*, int, int, int, int, hipStream_t, T*, size_t, int*); \
     template hipError_t gemm_nt_mu<T>(const T*, int, const T*, int, T*, int, int, int,                \
                                       const MuEpilogue<T>&, hipStream_t);                            \
     template hipError_t gemm_strided<T>(const T*, long, long, const T*, long, long, T*, long, long,  \

@@ -69,8 +69,10 @@ __global__ __launch_bounds__(256) void k_gl_tables(GlDims d, double* __restrict_
 }
 
 // P = mag * exp(1j * angle(S))   (zz_audio_utilities.py:284-286); S = [Re | Im] per row
-__global__ __launch_bounds__(256) void k_gl_project(const double* __restrict__ S, int lds_, const double* __restrict__ mag,
-                                                    long ldm, GlDims d, double* __restrict__ P) {
+// S may arrive as `splits` k-slabs (slab z at S + z * slab) that are summed here, in order
+__global__ __launch_bounds__(256) void k_gl_project(const double* __restrict__ S, int lds_, long slab, int splits,
+                                                    const double* __restrict__ mag, long ldm, GlDims d,
+                                                    double* __restrict__ P) {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (long)d.Tp * d.K2) return;
     const long t = gid / d.K2;
@@ -78,7 +80,11 @@ __global__ __launch_bounds__(256) void k_gl_project(const double* __restrict__ S
     double v = 0.0;
     if (t < d.T_ && c < 2 * d.nb) {
         const int k = c < d.nb ? c : c - d.nb;
-        const double re = S[t * lds_ + k], im = S[t * lds_ + d.nb + k];
+        double re = S[t * lds_ + k], im = S[t * lds_ + d.nb + k];
+        for (int z = 1; z < splits; ++z) {
+            re += S[z * slab + t * lds_ + k];
+            im += S[z * slab + t * lds_ + d.nb + k];
+        }
         const double ang = atan2(im, re);
         v = mag[t * ldm + k] * (c < d.nb ? cos(ang) : sin(ang));
     }
@@ -86,8 +92,8 @@ __global__ __launch_bounds__(256) void k_gl_project(const double* __restrict__ S
 }
 
 // x'[s] = sum over the frames f covering s of Fr[f][s - hop f]   (zz_audio_utilities.py:214-217)
-__global__ __launch_bounds__(256) void k_gl_overlap_add(const double* __restrict__ Fr, int ldf, GlDims d,
-                                                        double* __restrict__ xn) {
+__global__ __launch_bounds__(256) void k_gl_overlap_add(const double* __restrict__ Fr, int ldf, long slab, int splits,
+                                                        GlDims d, double* __restrict__ xn) {
     const long s = (long)blockIdx.x * 256 + threadIdx.x;
     if (s >= d.Lp) return;
     double acc = 0.0;
@@ -96,7 +102,11 @@ __global__ __launch_bounds__(256) void k_gl_overlap_add(const double* __restrict
         if (s - d.F + 1 <= 0) f0 = 0;
         long f1 = s / d.hop;                          // last frame with s - hop f >= 0
         if (f1 > d.T_ - 1) f1 = d.T_ - 1;
-        for (long f = f0; f <= f1; ++f) acc += Fr[f * ldf + (s - d.hop * f)];
+        for (long f = f0; f <= f1; ++f) {
+            double v = Fr[f * ldf + (s - d.hop * f)];
+            for (int z = 1; z < splits; ++z) v += Fr[z * slab + f * ldf + (s - d.hop * f)];    // k-slabs, in order
+            acc += v;
+        }
     }
     xn[s] = acc;                                      // zero beyond the signal: the padded GEMM rows read it
 }
@@ -158,13 +168,16 @@ hipError_t gl_run(const double* mag, long ldm, int T_, int F, int hop, int iters
     double* xn = xb;
     for (int it = 0; it < iters; ++it) {
         // S[t][:] = x[hop t : hop t + F] W_f     (rows of L overlap: row stride = hop)
-        e = gemm_nt<double>(xc, hop, Wf, d.K1, S, d.J1, d.Tp, d.J1, d.K1, s, split, nsplit);
+        int sp = 0;
+        e = gemm_nt<double>(xc, hop, Wf, d.K1, S, d.J1, d.Tp, d.J1, d.K1, s, split, nsplit, &sp);
         if (e != hipSuccess) return e;
         const long np_ = (long)d.Tp * d.K2;
-        hipLaunchKernelGGL(k_gl_project, dim3((unsigned)((np_ + 255) / 256)), dim3(256), 0, s, S, d.J1, mag, ldm, d, P);
-        e = gemm_nt<double>(P, d.K2, Wi, d.K2, Fr, d.J2, d.Tp, d.J2, d.K2, s, split, nsplit);
+        hipLaunchKernelGGL(k_gl_project, dim3((unsigned)((np_ + 255) / 256)), dim3(256), 0, s, sp ? split : S, d.J1,
+                           (long)d.Tp * d.J1, sp ? sp : 1, mag, ldm, d, P);
+        e = gemm_nt<double>(P, d.K2, Wi, d.K2, Fr, d.J2, d.Tp, d.J2, d.K2, s, split, nsplit, &sp);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_gl_overlap_add, dim3((unsigned)((d.Lp + 255) / 256)), dim3(256), 0, s, Fr, d.J2, d, xn);
+        hipLaunchKernelGGL(k_gl_overlap_add, dim3((unsigned)((d.Lp + 255) / 256)), dim3(256), 0, s, sp ? split : Fr,
+                           d.J2, (long)d.Tp * d.J2, sp ? sp : 1, d, xn);
         if (rmse_host) hipLaunchKernelGGL(k_gl_rmse, dim3(1), dim3(256), 0, s, xn, xc, d.L, tr + it);
         double* t = xc; xc = xn; xn = t;
     }

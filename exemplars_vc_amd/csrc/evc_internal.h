@@ -85,7 +85,9 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // scratch (optional, scratch_elems elements): lets a small-grid, long-K product be split over K.
 template <typename T>
 hipError_t gemm_nt(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int I, int J, int Kd,
-                   hipStream_t s, T* scratch = nullptr, size_t scratch_elems = 0);
+                   hipStream_t s, T* scratch = nullptr, size_t scratch_elems = 0, int* splits_out = nullptr);
+// splits_out: when the contraction was split over k into slabs in `scratch` (slab z at scratch + z * I * ldc),
+// *splits_out = their number and C is NOT written - the caller's next kernel sums them in order; else 0.
 // Same contraction with the multiplicative update as epilogue: C = mu(Hin, P, L R^T).
 template <typename T>
 hipError_t gemm_nt_mu(const T* L, int ldl, const T* R, int ldr, T* Hout, int I, int J, int Kd,
