@@ -184,12 +184,12 @@ hipError_t gemm_nt(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int 
         int splits = 1;
         const long slab = (long)I * ldc;
         if (scratch && ldc == J) {
-            // the largest split (<= 8) that divides the k-slabs evenly, keeps <= 512 workgroups and leaves every
+            // the largest split (<= 8) that divides the k-slabs evenly, keeps <= 1024 workgroups and leaves every
             // workgroup a worthwhile chunk (512 deep for long contractions, 64 for short ones such as the
             // 400-point DFTs of Griffin-Lim, whose 84 tiles would otherwise run 25 slabs each on a third of the CUs)
             const int nslabs = Kd / KS, chunk = Kd >= 1024 ? 512 : 64;
             for (int sp = 2; sp <= 8; ++sp)
-                if (nslabs % sp == 0 && blocks * sp <= 512 && Kd / sp >= chunk && (size_t)sp * slab <= scratch_elems)
+                if (nslabs % sp == 0 && blocks * sp <= 1024 && Kd / sp >= chunk && (size_t)sp * slab <= scratch_elems)
                     splits = sp;
         }
         if (splits == 1) return launch_nt<T, 64, 64, 32, 32, false>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s);
@@ -212,6 +212,13 @@ hipError_t gemm_nt_mu(const T* L, int ldl, const T* R, int ldr, T* Hout, int I, 
                       const MuEpilogue<T>& ep, hipStream_t s) {
     if (I <= 0 || J <= 0) return hipSuccess;
     if (I % 128 || J % 128 || Kd % KS || Kd <= 0) return hipErrorInvalidValue;
+    // Tile quantisation for one or two utterances: 128x128 tiles run in rounds of 256 (one per CU), 64x128
+    // tiles in rounds of 512 (two per CU, half the work each; a trailing all-padding row tile leaves at
+    // once).  C3 (768 x 8192): 384 full tiles = 2 rounds against 768 half tiles = 2 half rounds.
+    const long b128 = (long)(I / 128) * (J / 128), b64 = (long)(I / 64) * (J / 128);
+    const long t128 = 2 * ((b128 + 255) / 256), t64 = (b64 + 511) / 512;     // in half-tile rounds
+    if (I <= 2048 && t64 < t128)
+        return launch_nt<T, 64, 128, 32, 32, true>(L, ldl, R, ldr, Hout, ep.ldh, I, J, Kd, ep, s);
     return launch_nt<T, 128, 128, 64, 32, true>(L, ldl, R, ldr, Hout, ep.ldh, I, J, Kd, ep, s);
 }
 
