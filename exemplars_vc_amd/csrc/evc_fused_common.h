@@ -9,16 +9,6 @@ namespace evc {
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
-// tell the compiler a pointer is wave-uniform (it then lives in SGPRs and global accesses use the
-// saddr + per-lane-offset form)
-template <typename P>
-__device__ __forceinline__ P* uniform_ptr(P* p) {
-    const unsigned long long v = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
-    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return (P*)(((unsigned long long)hi << 32) | lo);
-}
-
 __host__ __device__ inline int fused_msteps(int M) { return M <= 16 ? (M + 3) / 4 : 4 + (M - 16 + 3) / 4; }
 // bin handled by k-step s for lane group q
 __device__ __forceinline__ int bin_of(int s, int q) { return 16 * (s >> 2) + q + 4 * (s & 3); }
