@@ -676,3 +676,44 @@ def test_two_processes_sharing_the_gpu_with_cooperative_launches(tmp_path):
     outs = [pr.communicate(timeout=600)[0].decode() for pr in procs]
     for pr, out in zip(procs, outs):
         assert pr.returncode == 0 and "WORST" in out, out[-2000:]
+
+
+@pytest.mark.parametrize("scale", [1e-200, 1e-140, 1e140, 1e200])
+@pytest.mark.parametrize("N,T", [(130, 40), (1024, 40), (4096, 300)])
+def test_extreme_magnitudes_take_the_exact_path(scale, N, T):
+    """Denominators outside [2^-250, 2^250] leave the fast path of the fused update (batch inversion would
+    overflow or underflow there): the exact path must give the reference's result at any magnitude float64
+    can hold.  General kernel (N=130), register-resident kernel (N=1024, T=300 -> one workgroup per tile)
+    and its cooperative launch (N=4096, T=300 is 19 tiles)."""
+    import exemplars_vc_amd as evc
+    o = oracle()
+    p = o.synth_problem(25, N, T, seed=N)
+    X = p["X"] * scale
+    K = 12
+    want, _, _ = o.sklearn_mu_fixed_dictionary(np.ascontiguousarray(X.T), np.ascontiguousarray(p["A"].T), K, 0.0)
+    got = evc.solve_activations(p["A"], X, iters=K, eps_mode="zero_replace", init="sklearn")
+    assert np.isfinite(got).all()
+    assert_close64(got, want.T, f"scale {scale:g} N={N}")
+
+
+@pytest.mark.parametrize("N", [130, 1024, 4096])
+def test_nan_and_inf_frames_propagate_like_the_reference(N):
+    """pymf and nmf_tool validate nothing: a NaN or infinite frame yields NaN activations for that frame and
+    leaves every other frame untouched (frames are independent columns).  Same NaN pattern, same finite
+    values, on the general, register-resident and cooperative kernels."""
+    import exemplars_vc_amd as evc
+    o = oracle()
+    T, K = 50, 8
+    p = o.synth_problem(25, N, T, seed=3 * N)
+    X = p["X"].copy()
+    X[:, 7] = np.nan
+    X[3, 21] = np.inf
+    H0 = np.random.default_rng(N).random((N, T)) + 1e-4
+    with np.errstate(all="ignore"):
+        want = o.mu_solve(p["A"], X, H0, K, eps_mode=o.EPS_ADD, eps=1e-9)
+    got = evc.solve_activations(p["A"], X, H0, iters=K, eps_mode="add", eps=1e-9)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.isnan(got[:, 7]).all() and np.isnan(got[:, 21]).all()      # inf * 0-weight bins -> NaN after one step
+    ok = ~np.isnan(want)
+    r = np.abs(got[ok] - want[ok]) / np.abs(want[ok])
+    assert r.max() <= RTOL64
