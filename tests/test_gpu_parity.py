@@ -717,3 +717,33 @@ def test_nan_and_inf_frames_propagate_like_the_reference(N):
     ok = ~np.isnan(want)
     r = np.abs(got[ok] - want[ok]) / np.abs(want[ok])
     assert r.max() <= RTOL64
+
+
+def test_more_than_2_to_31_activations():
+    """N x T beyond 2^31 elements (17 GB of float64 activations, all on the device): every index in the pack,
+    solve, export and synthesis kernels must be 64-bit.  Frames are independent columns, so the first and the
+    last 48 frames of the big batch must equal the same frames solved alone (same launch mode, bitwise)."""
+    import torch
+    import exemplars_vc_amd as evc
+    N, M, T, K = 16384, 25, 131200, 3
+    assert N * T > 2 ** 31
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 * 2 ** 30:
+        pytest.skip("needs 60 GB of free device memory")
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    A = torch.rand(N, M, generator=g, device=dev, dtype=torch.float64) + 1e-3
+    B = torch.rand(N, M, generator=g, device=dev, dtype=torch.float64)
+    X = torch.rand(T, M, generator=g, device=dev, dtype=torch.float64) + 1e-3
+    kw = dict(layout="frame_major", iters=K, eps_mode="zero_replace", init="const", init_value=0.01,
+              cooperative=False)
+    H, Y = evc.convert(A, X, B, **kw)
+    assert H.shape == (T, N) and Y.shape == (T, M)
+    for sl in (slice(0, 48), slice(T - 48, T), slice(65536 + 16, 65536 + 64)):
+        Hs, Ys = evc.convert(A, X[sl].contiguous(), B, **kw)
+        assert torch.equal(H[sl], Hs)
+        assert torch.allclose(Y[sl], Ys, rtol=1e-12, atol=0)
+    assert bool(torch.isfinite(H[-1]).all()) and float(H.min()) >= 0.0
+    del H, Y
+    evc.release_workspaces()
+    torch.cuda.empty_cache()
