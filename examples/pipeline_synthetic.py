@@ -89,8 +89,12 @@ def main(n_pairs=6, seconds=1.0, gl_iters=60, verbose=True):
         t_conv = time.perf_counter() - t1
         np.random.seed(0)
         t2 = time.perf_counter()
-        wav = griffin_lim.reconstruct_signal_griffin_lim(converted.astype(np.float64), 400, 80, gl_iters, verbose=False)
+        wav, wav_path = griffin_lim.synthesize2(converted, FS, "converted", out_dir=os.path.join(root, "wav"),
+                                                iterations=gl_iters)
         t_gl = time.perf_counter() - t2
+        from scipy.io import wavfile
+        sr_back, wav_back = wavfile.read(wav_path)
+        assert sr_back == FS and wav_back.dtype == np.float32 and len(wav_back) == len(wav)
 
     want = np.abs(features.stft_features(truth)["real"])
     d_before = spectral_distance(np.abs(tobe["real"]), want)

@@ -24,3 +24,21 @@ def reconstruct_signal_griffin_lim(magnitude_spectrogram, fft_size, hopsamp, ite
         for i, diff in enumerate(rmse):
             print('Reconstruction iteration: {}/{} RMSE: {} '.format(i + 1, iterations, diff))
     return x
+
+
+def synthesize2(stft_mag, fs, filename=None, *, out_dir="wav", iterations=300, frame_length=400, hop_length=80,
+                device=None, verbose=False):
+    """`synthesize2(stft_mag, fs, filename)` of 04_align_n_nmf.py:181-191: Griffin-Lim on |stft_mag| (300
+    iterations, frame 400, hop 80) and the result written to `wav/<filename>.wav`.  librosa.output.write_wav
+    (absent here) stored the float signal as a 32-bit float wav without normalising; scipy.io.wavfile does the
+    same.  Returns (y, path); filename=None skips the file."""
+    y = reconstruct_signal_griffin_lim(np.abs(np.asarray(stft_mag, dtype=np.float64)), frame_length, hop_length,
+                                       iterations, device=device, verbose=verbose)
+    path = None
+    if filename is not None:
+        import os
+        from scipy.io import wavfile
+        os.makedirs(out_dir, exist_ok=True)
+        path = os.path.join(out_dir, f"{filename}.wav")
+        wavfile.write(path, int(fs), y.astype(np.float32))
+    return y, path
