@@ -260,7 +260,7 @@ def main():
         if args.loss != "frobenius":
             res["config"]["loss"] = args.loss
             res["roofline"]["note"] = "KL update: flop count of the Frobenius update is NOT applicable; see value only"
-        if not args.no_cpu and args.loss == "frobenius":
+        if not args.no_cpu and args.loss == "frobenius" and world == 1:   # CPU leg: rank 0 at N=1 only
             cpu, (p, act_cpu, Y_cpu) = cpu_baseline(M, N, K, 20190131, args.cpu_frames)
             res["cpu_baseline"] = cpu
             # conservative: against the faster of the oracle port and the installed scikit-learn
