@@ -85,7 +85,7 @@ Workspace<T> carve(void* base, const Dims& d, int algo, int n_slots, bool fused)
         w.fb.Xp = c.take<double>(w.fl.xp);
         w.fb.Hp = c.take<double>(w.fl.hp);
         w.fb.Vp = c.take<double>(w.fl.vp);
-        w.fb.coop_buf = c.take<double>((size_t)2 * COOP_MAX_TILES * 512);
+        w.fb.coop_buf = c.take<double>((size_t)2 * (ALL_MAX_WGS > COOP_MAX_TILES ? ALL_MAX_WGS : COOP_MAX_TILES) * 512);
         w.fb.coop_cnt = c.take<int>(COOP_MAX_TILES + 1);
         w.fb.coop_c = 1;
     }
@@ -191,15 +191,23 @@ int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_sol
     // (k_fused_res COOP); reserved bit 2 switches it off
     FusedBuffers fb = w.fb;
     fb.coop_c = 1;
-    if (!(o.reserved & 4) && c_override == 0 && fused_res_supported(d.N, o.eps_mode, exact_div)) {
-        int dev = 0, cus = 0;
-        HIP_TRY(hipGetDevice(&dev));
-        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-        fb.coop_c = fused_res_coop_factor(w.fl.NT, w.fl.TT, cus);
+    fb.all_c = 0;
+    int dev = 0, cus = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    fb.n_cus = cus;
+    // every activation and numerator tile register-resident, NT / 32 workgroups per frame tile (k_fused_all);
+    // reserved bit 4 switches that kernel off, bit 2 every form of inter-workgroup exchange
+    if (c_override == 0 && !(o.reserved & 16)) {
+        const int c = fused_all_members(w.fl.NT, d.N, o.eps_mode, exact_div, o.loss);
+        if (c == 1 || (c > 1 && !(o.reserved & 4))) fb.all_c = c;
     }
+    if (!fb.all_c && !(o.reserved & 4) && c_override == 0 && fused_res_supported(d.N, o.eps_mode, exact_div))
+        fb.coop_c = fused_res_coop_factor(w.fl.NT, w.fl.TT, cus);
+    const bool exchanges = fb.coop_c > 1 || fb.all_c > 1;
     int* coop_abort = fb.coop_cnt + COOP_MAX_TILES;
     // reserved bit 3 (tests): start with the abort flag raised, so that the call takes the retry path below
-    if (fb.coop_c > 1) HIP_TRY(hipMemsetAsync(coop_abort, (o.reserved & 8) ? 1 : 0, sizeof(int), s));
+    if (exchanges) HIP_TRY(hipMemsetAsync(coop_abort, (o.reserved & 8) ? 1 : 0, sizeof(int), s));
     int first = 1;
     if (o.check_every > 0 && o.stop_rule == EVC_STOP_SKLEARN) {   // error_at_init
         HIP_TRY(fused_iterate(w.fl, fb, w.u, d.N, d.T_, 0, 1, 1, w.err2, o.eps_mode, o.eps, o.l1,
@@ -222,7 +230,7 @@ int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_sol
                               o.tol, s));
     }
     if (o.ev_loop_stop) HIP_TRY(hipEventRecord((hipEvent_t)o.ev_loop_stop, s));
-    *coop_used = fb.coop_c > 1 ? 1 : 0;     // the caller checks the abort flag (one host round trip)
+    *coop_used = exchanges ? 1 : 0;         // the caller checks the abort flag (one host round trip)
     return ST_OK;
 }
 
@@ -441,7 +449,7 @@ static bool f32_rides_f64(int M, int N, int T, int algo, int reserved) {
 }
 static size_t f32_staging_bytes(int M, int Mb, int N, int T) {
     const size_t n = (size_t)N * M + (size_t)T * M + (size_t)T * N + (size_t)N * Mb + (size_t)T * Mb;
-    return n * sizeof(double) + 6 * 256;
+    return ((n * sizeof(double) + 6 * 256) + 255) & ~size_t(255);   // the inner workspace starts 256-byte aligned
 }
 
 size_t evc_workspace_bytes(int M, int Mb, int N, int T, int n_utt, int dtype, int algo) {

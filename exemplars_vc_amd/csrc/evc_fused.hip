@@ -273,7 +273,11 @@ __global__ __launch_bounds__(NW * 64) void k_fused_mu(FusedArgs a) {
     bool all_live = true;
 #pragma unroll
     for (int c = 0; c < C; ++c) all_live = all_live && live[c];
-    const bool masked = !__syncthreads_and(all_live) || (a.N & 15) != 0;
+    // (whole all-padding exemplar tiles exist once fused_layout pads NT to rounds of 8 wavefronts: under the
+    // guarded modes 0 * 0 / guard keeps them at zero, the unguarded mode would turn them - and through V'
+    // every frame of the workgroup - into NaN)
+    const bool masked = !__syncthreads_and(all_live) || (a.N & 15) != 0 ||
+                        (a.eps_mode == EVC_EPS_NONE && 16L * NT > a.N);
     const double eps = a.eps;
 
     auto sweep = [&](auto mul_first_tag, auto masked_tag, auto kl_tag) {
@@ -389,6 +393,9 @@ FusedLayout fused_layout(int M, int N, int T_) {
     // rounds of the 8 wavefronts; padding exemplars have zero dictionary columns and zero activations, and
     // 0 * 0 / guard keeps them at zero under every guarded eps mode
     f.NT = N >= 1024 ? round_up(N, 128) / 16 : (N + 15) / 16;
+    // k_fused_all wants whole workgroups of 32 tiles (512 exemplars): pad to that when it costs <= 7 %
+    const int nt32 = round_up(f.NT, 32);
+    if (nt32 * 100L <= f.NT * 107L) f.NT = nt32;
     f.TT = (T_ + 15) / 16;
     f.TTp = round_up(f.TT, 4);
     f.a1 = (size_t)f.NT * ((f.msteps + 1) & ~1) * 64;
@@ -492,8 +499,10 @@ hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttS
     a.iters = iters; a.first = first; a.write_err = write_err; a.skip_all_live = 0; a.force_live = 0;
     a.loss = loss; a.exact_div = exact_div;
     a.eps_mode = eps_mode; a.eps = eps; a.l1 = l1;
-    a.coop_c = 1; a.coop_buf = nullptr; a.coop_cnt = nullptr; a.coop_abort = nullptr;
-    const bool resident = c_req == 0 && fused_res_supported(N, eps_mode, exact_div);
+    a.coop_c = 1; a.coop_buf = nullptr; a.coop_cnt = nullptr; a.coop_abort = nullptr; a.groups = 0;
+    const bool all_res = c_req == 0 && b.all_c >= 1 && b.coop_buf && b.coop_cnt &&
+                         fused_all_members(f.NT, N, eps_mode, exact_div, loss) == b.all_c;
+    const bool resident = all_res || (c_req == 0 && fused_res_supported(N, eps_mode, exact_div));
     if (!resident) return launch_general(f, a, c_req, s);
     if (first) {                 // V = A H (and the residual at init) by the general kernel's pre-pass
         FusedArgs p = a;
@@ -504,11 +513,19 @@ hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttS
         a.first = 0;
     }
     if (iters == 0) return hipSuccess;
-    if (b.coop_c > 1 && b.coop_buf && b.coop_cnt) {
-        a.coop_c = b.coop_c; a.coop_buf = b.coop_buf; a.coop_cnt = b.coop_cnt;
+    hipError_t e;
+    if (all_res) {
+        a.coop_c = b.all_c; a.coop_buf = b.coop_buf; a.coop_cnt = b.coop_cnt;
         a.coop_abort = b.coop_cnt + COOP_MAX_TILES;
+        e = fused_all_launch(f.msteps, a, b.n_cus, s);
+        a.coop_c = 1;            // the general kernel behind it takes no part in any exchange
+    } else {
+        if (b.coop_c > 1 && b.coop_buf && b.coop_cnt) {
+            a.coop_c = b.coop_c; a.coop_buf = b.coop_buf; a.coop_cnt = b.coop_cnt;
+            a.coop_abort = b.coop_cnt + COOP_MAX_TILES;
+        }
+        e = fused_res_launch(f.msteps, a, s);
     }
-    hipError_t e = fused_res_launch(f.msteps, a, s);
     if (e != hipSuccess || all_live_known) return e;
     a.skip_all_live = 1;         // workgroups holding frames of stopped utterances
     return launch_general(f, a, 1, s);
@@ -525,7 +542,7 @@ hipError_t fused_synthesize(const FusedLayout& fB, const double* B2p, const doub
     a.err2 = nullptr; a.frame_utt = u.frame_utt; a.active = u.active;
     a.NT = fB.NT; a.TT = fB.TT; a.N = N; a.T_ = T_;
     a.iters = 0; a.first = 1; a.write_err = 0; a.skip_all_live = 0; a.force_live = 1; a.loss = EVC_LOSS_FROBENIUS; a.exact_div = 0;
-    a.coop_c = 1; a.coop_buf = nullptr; a.coop_cnt = nullptr; a.coop_abort = nullptr;
+    a.coop_c = 1; a.coop_buf = nullptr; a.coop_cnt = nullptr; a.coop_abort = nullptr; a.groups = 0;
     a.eps_mode = EVC_EPS_ADD; a.eps = 0; a.l1 = 0;
     hipError_t e = dispatch_msteps<1>(fB.msteps, a, s);
     if (e != hipSuccess) return e;

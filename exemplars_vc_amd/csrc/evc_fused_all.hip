@@ -1,0 +1,371 @@
+// All-resident variant of the fused FACTORED kernel (float64, M <= 32): nothing streams.
+//
+// k_fused_res keeps half of a 16-frame block's activations in registers and recomputes the numerator
+// tiles P = A_j^T X in every iteration (7 of the 22 MFMAs of a unit at M = 25), because one workgroup
+// owns all N exemplars of its frames: at N = 4096 that is 512 KiB of H plus 512 KiB of P per 16 frames,
+// more than a CU holds.  Here a frame tile is shared by C "members" (a group), each owning 32 exemplar
+// tiles (512 exemplars): 4 wavefronts x 8 tiles, whose activations AND numerators stay in VGPRs (128 of
+// the 256 registers of a wavefront) for all iterations of a frame tile.  A unit is then 15 MFMAs
+// (D = A_j^T V: 7, V' += A_j H'_j: 8) instead of 20.5 on average, and the only memory traffic of the loop
+// is the dictionary fragments (L2) and the exchange of the partial V' between the members of a group.
+//
+// The exchange costs a memory round trip per iteration (measured 3.5 us against a 3.8 us sweep), so it has
+// to hide behind matrix work of ANOTHER frame tile.  Two free-running 4-wavefront workgroups per CU do not
+// do that: coupled through their peers they fall into lock step - both sweep together (sharing the matrix
+// pipes), then both wait together (measured: 10.9 us per iteration, 7.3 + 3.5).  So one workgroup of 8
+// wavefronts holds TWO members, of two different groups: wavefronts 0-3 ("half" 0) and 4-7 (half 1; wave
+// w and w + 4 share a SIMD).  They alternate by construction: in every step one half sweeps while the other
+// exchanges, and a workgroup barrier closes the step, so a SIMD's matrix pipe always belongs to exactly one
+// wavefront and the exchange of one frame tile always runs beside the sweep of the other.
+//
+//   step      0        1        2        3      ...   2K-1      2K
+//   half 0  sweep 0   exch    sweep 1   exch    ...   exch       -
+//   half 1    -      sweep 0   exch    sweep 1  ...  sweep K-1  exch
+//
+// The grid is persistent: one workgroup per CU, G = 2 floor(#CUs / C) groups walk the frame tiles g, g + G,
+// ... (all members of a group walk the same list in lock step), so every member of every group is resident
+// for the whole launch whatever the batch size.
+//
+// Exchange: after the sweep the half's wavefronts leave their partial V' in LDS; in the exchange step every
+// thread sums its elements over the 4 wavefronts in fixed order, publishes them with agent-scope relaxed
+// atomic stores (sc1: past the non-coherent per-XCD L2s) and fetches the same elements of its peers; the
+// lowest mantissa bit of a word is the epoch of the buffer, so data and arrival travel in one word (each
+// wavefront first watches one word per peer, so that the bulk fetch normally succeeds at once).  Every
+// member sums the C words of an element in member order: all obtain the bitwise identical V'.  Two buffers
+// alternate by exchange parity (a member overwrites a buffer two exchanges later, after it has read every
+// peer's words of the exchange in between, which the peer published after reading this member's words of
+// the exchange before).  Every wait is bounded; a member that gives up raises coop_abort, everybody leaves,
+// and the host redoes the solve without inter-workgroup communication (evc_api.hip).
+//
+// Requirements (the host checks them, fused_all_members): guarded eps mode, fast quotients, Frobenius
+// loss, NT a multiple of 32.  Frame tiles whose frames are not all live are left to the general kernel
+// (skip_all_live), like in k_fused_res.
+#include "evc_fused_common.h"
+
+namespace evc {
+
+constexpr int AW = 4;                  // wavefronts per half
+constexpr int AKT = 8;                 // exemplar tiles per wavefront, all register-resident
+constexpr int ATILES = AW * AKT;       // exemplar tiles per member
+constexpr int ATHREADS = 2 * AW * 64;  // two halves per workgroup
+constexpr unsigned ALL_POLL_LIMIT = 1u << 17;
+
+#ifdef EVC_ALL_TIMING   // diagnostic build only (tools/ubench/fused_all_bench.hip); no stamp executes in the library
+#define EVC_STAMP(i)                                                                                             \
+    do {                                                                                                         \
+        if (a.dbg && tt0 == g - half && lane == 0 && w == 0)                                                     \
+            a.dbg[(((long)blockIdx.x * 2 + half) * (2 * a.iters + 1) + step) * 4 + (i)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define EVC_STAMP(i)
+#endif
+
+template <int MSTEPS, int C>
+__global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
+    constexpr int MT = MSTEPS > 4 ? 2 : 1;
+    constexpr int E = MT * 4 * 64;               // stride of one V image (accumulator order)
+    constexpr int NE = MSTEPS * 64;              // elements of V actually used
+    constexpr int MSP = (MSTEPS + 1) & ~1;       // k-steps padded to pairs in A1p
+    __shared__ double s_red[2][AW * E];          // partial V' of every wavefront, per half
+    __shared__ double s_v[2][E];                 // V, B-operand order
+    __shared__ double s_x[2][E];                 // X, B-operand order
+    __shared__ int s_fail;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = w8 >> 2, w = w8 & 3, th = tid & (AW * 64 - 1);
+    const int member = blockIdx.x % C;
+    const int g = 2 * (blockIdx.x / C) + half;           // the group this half is a member of
+    double* const red = s_red[half];
+    double* const vL = s_v[half];
+    double* const xL = s_x[half];
+    const double* __restrict__ A1p = a.A1p;
+    const double* __restrict__ A2p = a.A2p;
+    f64x2* __restrict__ Hp = a.Hp;
+    const int NT = a.NT;
+    const long tile0 = (long)member * ATILES + w;       // this wavefront's tiles: tile0 + AW * k
+    const unsigned ul = (unsigned)lane;
+    // Tile base addresses are wave-uniform (SGPR base + unsigned per-lane offset).  `sw` is an opaque zero
+    // refreshed once per sweep so that the 16 tile addresses are re-derived with scalar adds instead of being
+    // hoisted out of the loops as per-lane 64-bit addresses (32 VGPRs).
+    long sw = 0;
+
+    auto load_a1 = [&](double (&a1)[MSTEPS], int k) {
+        const f64x2* t = reinterpret_cast<const f64x2*>(A1p + (tile0 + sw + AW * k) * (MSP * 64));
+#pragma unroll
+        for (int s = 0; s < MSTEPS; s += 2) {
+            if (s + 1 < MSTEPS) {
+                const f64x2 v = t[(s >> 1) * 64 + ul];
+                a1[s] = v[0];
+                a1[s + 1] = v[1];
+            } else {
+                a1[s] = reinterpret_cast<const double*>(&t[(s >> 1) * 64 + ul])[0];
+            }
+        }
+    };
+    auto load_a2 = [&](double (&a2)[MT][4], int k) {
+        const f64x2* t = reinterpret_cast<const f64x2*>(A2p + (tile0 + sw + AW * k) * (MT * 256));
+#pragma unroll
+        for (int u = 0; u < MT; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+                const f64x2 v = t[(u * 2 + (r >> 1)) * 64 + ul];
+                a2[u][r] = v[0];
+                a2[u][r + 1] = v[1];
+            }
+    };
+
+    const int mode = a.eps_mode;
+    const double eps = a.eps;
+    const double d0 = a.l1 + (mode == EVC_EPS_ADD ? a.eps : 0.0);
+    const f64x4 dinit = {d0, d0, d0, d0};
+    const unsigned lo = fast_lo(mode, eps);
+    unsigned seq = 0;                            // exchanges done by this half's group so far
+    if (tid == 0) s_fail = 0;
+
+    for (long tt0 = g - half; tt0 < a.TT; tt0 += a.groups) {     // half 0's tile decides (it has the lower index)
+        const long tt = tt0 + half;
+        bool valid;
+        {
+            const long t = 16 * tt + (lane & 15);
+            int u = -1;
+            if (tt < a.TT && t < a.T_) u = a.frame_utt[t];
+            // padding frames count as live; a tile beyond the batch, or one holding frames of a stopped
+            // utterance (left to the general kernel, skip_all_live), is not processed
+            const bool live = tt < a.TT && ((t >= a.T_) || ((u >= 0) && (a.active[u] != 0)));
+            const int v0 = __syncthreads_and(half == 0 ? live : true);
+            const int v1 = __syncthreads_and(half == 1 ? live : true);
+            valid = (half ? v1 : v0) != 0;
+        }
+        HTile h[AKT];
+        f64x4 p[AKT];
+        double a1[MSTEPS], a2[MT][4];
+        if (valid) {
+            for (int e = th; e < E; e += AW * 64) {
+                const int s = e >> 6, l = e & 63;
+                const bool in = s < MSTEPS;
+                xL[e] = in ? a.Xp[(tt * MSTEPS + s) * 64 + l] : 0.0;
+                vL[e] = in ? a.Vp[(tt * 8 + s) * 64 + l] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < AKT; ++k) {
+                const f64x2* t = Hp + (tt * NT + tile0 + AW * k) * 128;
+                const f64x2 h01 = t[ul], h23 = t[ul + 64];
+                h[k][0] = h01[0]; h[k][1] = h01[1]; h[k][2] = h23[0]; h[k][3] = h23[1];
+            }
+        }
+        __syncthreads();
+        if (valid) {                             // numerator tiles, once per frame tile
+            double x[MSTEPS];
+#pragma unroll
+            for (int s = 0; s < MSTEPS; ++s) x[s] = xL[s * 64 + lane];
+            load_a1(a1, 0);
+#pragma unroll
+            for (int k = 0; k < AKT; ++k) {
+                f64x4 acc = {0, 0, 0, 0};
+#pragma unroll
+                for (int s = 0; s < MSTEPS; ++s) acc = Mma<double>::mma(a1[s], x[s], acc);
+                load_a1(a1, (k + 1) % AKT);
+                p[k] = acc;
+            }
+        }
+
+        for (int step = 0; step <= 2 * a.iters; ++step) {
+            const bool mine = (step & 1) == half;                 // this half's turn on the matrix pipes
+            EVC_STAMP(0);
+            if (valid && mine && step < 2 * a.iters) {
+                // ---------------- sweep: h <- h p / (A_j^T V), V' += A_j h over the 8 resident tiles
+                asm volatile("" : "+s"(sw));
+                double v[MSTEPS];
+#pragma unroll
+                for (int s = 0; s < MSTEPS; ++s) v[s] = vL[s * 64 + lane];
+                f64x4 vn[MT];
+#pragma unroll
+                for (int u = 0; u < MT; ++u) vn[u] = f64x4{0, 0, 0, 0};
+#pragma unroll
+                for (int k = 0; k < AKT; ++k) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_a2(a2, k);
+                    f64x4 d = dinit;
+#pragma unroll
+                    for (int s = 0; s < MSTEPS; ++s) d = Mma<double>::mma(a1[s], v[s], d);
+                    load_a1(a1, (k + 1) % AKT);      // the next unit's (or the next sweep's first) fragments
+                    __builtin_amdgcn_sched_barrier(0);
+                    mu_tile<false>(h[k], p[k], d, mode, eps, lo);
+#pragma unroll
+                    for (int u = 0; u < MT; ++u)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) vn[u] = Mma<double>::mma(a2[u][r], h[k][r], vn[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < MT; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (u * 4 + r < MSTEPS) red[w * E + (u * 4 + r) * 64 + lane] = vn[u][r];
+            } else if (valid && !mine && step > 0) {
+                // ---------------- exchange: V' = sum over wavefronts and members, no barrier inside
+                const int e0 = th, e1 = th + AW * 64;
+                const bool has1 = e1 < NE;
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int ww = 0; ww < AW; ++ww) {
+                    s0 += red[ww * E + e0];
+                    s1 += red[ww * E + (has1 ? e1 : e0)];
+                }
+                if (C > 1) {
+                    long long* xb = reinterpret_cast<long long*>(a.coop_buf) +
+                                    ((size_t)(seq & 1) * a.groups + g) * (size_t)(C * 512);
+                    const long long tag = (seq >> 1) & 1;        // a buffer is reused every second exchange
+                    const long long m0 = (__double_as_longlong(s0) & ~1LL) | tag;
+                    const long long m1 = (__double_as_longlong(s1) & ~1LL) | tag;
+                    __hip_atomic_store(xb + member * 512 + e0, m0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (has1) __hip_atomic_store(xb + member * 512 + e1, m1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    bool ok = true;
+                    unsigned polls = 0;
+                    {   // watch one word per peer (lane m <-> member m): C - 1 loads per poll and wavefront
+                        const long long* sp = xb + (lane < C ? lane : 0) * 512 + (NE - 1);
+                        for (;;) {
+                            const long long b = __hip_atomic_load(sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const bool ready = lane >= C || lane == member || (b & 1) == tag;
+                            if (__all(ready)) break;
+                            if (++polls > ALL_POLL_LIMIT ||
+                                ((polls & 63) == 0 &&
+                                 __hip_atomic_load(a.coop_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                                ok = false;
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                    }
+                    // every thread fetches its elements of all members; each word carries its own epoch bit, so
+                    // a word that lags behind the watched one is simply fetched again
+                    long long b0[C] = {}, b1[C] = {};
+                    polls = 0;
+                    while (ok) {
+#pragma unroll
+                        for (int m = 0; m < C; ++m)
+                            b0[m] = __hip_atomic_load(xb + m * 512 + e0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                        for (int m = 0; m < C; ++m)     // (threads without a second element re-read their first)
+                            b1[m] = __hip_atomic_load(xb + m * 512 + (has1 ? e1 : e0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        long long bad = 0;
+#pragma unroll
+                        for (int m = 0; m < C; ++m) {
+                            b0[m] = (m == member) ? m0 : b0[m];
+                            b1[m] = (m == member) ? m1 : b1[m];
+                            bad |= (b0[m] ^ tag) | (b1[m] ^ tag);
+                        }
+                        if ((bad & 1) == 0) break;
+                        if (++polls > ALL_POLL_LIMIT ||
+                            ((polls & 63) == 0 &&
+                             __hip_atomic_load(a.coop_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                            ok = false;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    s0 = 0.0; s1 = 0.0;
+#pragma unroll
+                    for (int m = 0; m < C; ++m) {                 // member order: identical on every member
+                        s0 += __longlong_as_double(b0[m] & ~1LL);
+                        s1 += __longlong_as_double(b1[m] & ~1LL);
+                    }
+                    ++seq;
+                    if (!ok) s_fail = 1;
+                }
+                vL[e0] = s0;
+                if (has1) vL[e1] = s1;
+            }
+            EVC_STAMP(1);
+            __syncthreads();
+            EVC_STAMP(2);
+            if (C > 1 && s_fail) {               // a peer never showed up: void the launch, let everybody leave
+                if (tid == 0) __hip_atomic_store(a.coop_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+        }
+
+        if (valid) {
+#pragma unroll
+            for (int k = 0; k < AKT; ++k) {
+                f64x2* t = Hp + (tt * NT + tile0 + AW * k) * 128;
+                t[ul] = f64x2{h[k][0], h[k][1]};
+                t[ul + 64] = f64x2{h[k][2], h[k][3]};
+            }
+            // carry V to the next launch; per-frame squared residual of the final activations
+            if (member == 0) {                   // every member holds the same V: one writes it
+                for (int e = th; e < NE; e += AW * 64) a.Vp[(tt * 8 + (e >> 6)) * 64 + (e & 63)] = vL[e];
+                if (a.write_err && w == 0) {
+                    double e = 0.0;
+#pragma unroll
+                    for (int s = 0; s < MSTEPS; ++s) {
+                        const double x = xL[s * 64 + lane], vv = vL[s * 64 + lane];
+                        e += (x - vv) * (x - vv);
+                    }
+                    e += __shfl_xor(e, 16, 64);  // the 4 lane groups hold one frame's bins
+                    e += __shfl_xor(e, 32, 64);
+                    const long t = 16 * tt + lane;
+                    if (lane < 16 && t < a.T_) a.err2[t] = e;
+                }
+            }
+        }
+        __syncthreads();                         // xL / vL are rewritten for the next frame tile
+    }
+}
+
+template <int MSTEPS, int C>
+static hipError_t launch_all(FusedArgs a, int n_cus, hipStream_t s) {
+    int occ = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fused_all<MSTEPS, C>, ATHREADS, 0);
+    if (e != hipSuccess) return e;
+    if (occ < 1) return hipErrorInvalidValue;
+    long resident = n_cus;                       // one workgroup (two members) per CU
+    if (2 * resident > ALL_MAX_WGS) resident = ALL_MAX_WGS / 2;
+    int pairs = (int)(resident / C);             // pairs of groups
+    const int want = (a.TT + 1) / 2;
+    if (pairs > want) pairs = want;
+    if (pairs < 1) return hipErrorInvalidValue;
+    a.groups = 2 * pairs;
+    if (C > 1) {
+        // stale words must not carry the epoch bit of the first two exchanges (0): fill with ones
+        e = hipMemsetAsync(a.coop_buf, 0xFF, sizeof(double) * 2 * (size_t)a.groups * C * 512, s);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_fused_all<MSTEPS, C>), dim3((unsigned)(pairs * C)), dim3(ATHREADS), 0, s, a);
+    return hipGetLastError();
+}
+
+template <int MSTEPS>
+static hipError_t pick_c(const FusedArgs& a, int n_cus, hipStream_t s) {
+    switch (a.NT / ATILES) {
+        case 1: return launch_all<MSTEPS, 1>(a, n_cus, s);
+        case 2: return launch_all<MSTEPS, 2>(a, n_cus, s);
+        case 4: return launch_all<MSTEPS, 4>(a, n_cus, s);
+        case 8: return launch_all<MSTEPS, 8>(a, n_cus, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// members per frame tile the all-resident kernel would use for this problem, 0 if it does not apply
+int fused_all_members(int NT, int N, int eps_mode, int exact_div, int loss) {
+    if (eps_mode == EVC_EPS_NONE || exact_div || loss != EVC_LOSS_FROBENIUS) return 0;
+    if (NT % ATILES) return 0;
+    const int c = NT / ATILES;
+    return (c == 1 || c == 2 || c == 4 || c == 8) ? c : 0;
+}
+
+hipError_t fused_all_launch(int msteps, const FusedArgs& a, int n_cus, hipStream_t s) {
+    if (a.NT % ATILES || !a.coop_buf || !a.coop_abort) return hipErrorInvalidValue;
+    switch (msteps) {
+        case 1: return pick_c<1>(a, n_cus, s);
+        case 2: return pick_c<2>(a, n_cus, s);
+        case 3: return pick_c<3>(a, n_cus, s);
+        case 4: return pick_c<4>(a, n_cus, s);
+        case 5: return pick_c<5>(a, n_cus, s);
+        case 6: return pick_c<6>(a, n_cus, s);
+        case 7: return pick_c<7>(a, n_cus, s);
+        case 8: return pick_c<8>(a, n_cus, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace evc

@@ -41,6 +41,10 @@ struct FusedArgs {
     double* coop_buf;        // [2][TT][coop_c][E]
     int* coop_cnt;           // [TT] arrival counters, zero at launch
     int* coop_abort;         // set when a wait timed out: the launch's results are void
+    int groups;              // k_fused_all: groups of coop_c workgroups walking the frame tiles (set by the launcher)
+#ifdef EVC_ALL_TIMING
+    long long* dbg;          // tools/ubench/fused_all_bench.hip: s_memtime stamps of the first round's steps
+#endif
 };
 
 // One tile's four activations of a lane.  The elements sit 16 bytes apart on purpose: stored back to
@@ -136,6 +140,8 @@ __device__ __forceinline__ void mu_tile(HT& h, const f64x4& p, const f64x4& dacc
 }
 
 hipError_t fused_res_launch(int msteps, const FusedArgs& a, hipStream_t s);
+// evc_fused_all.hip: every activation and numerator tile register-resident, NT / 32 workgroups per frame tile
+hipError_t fused_all_launch(int msteps, const FusedArgs& a, int n_cus, hipStream_t s);
 
 // per-frame share of 2 KL(X || A H) from the B-operand images of X and V held by one lane
 // (sklearn _nmf.py:136-160: log term only where x > eps, V floored at eps there, plus sum(V))

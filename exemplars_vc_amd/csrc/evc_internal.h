@@ -146,13 +146,18 @@ struct FusedLayout {
     size_t a1, a2, xp, hp, vp;   // element counts of the packed arrays
 };
 constexpr int COOP_MAX_TILES = 256;       // frame tiles x cooperating workgroups never exceeds this (one per CU)
+constexpr int ALL_MAX_WGS = 1024;         // resident workgroups of k_fused_all the exchange buffers are sized for
 int fused_res_coop_factor(int NT, int TT, int n_cus);
+// workgroups per frame tile the all-resident kernel (k_fused_all) uses for this problem; 0: it does not apply
+int fused_all_members(int NT, int N, int eps_mode, int exact_div, int loss);
 bool fused_res_supported(int N, int eps_mode, int exact_div);
 struct FusedBuffers {
     double *A1p, *A2p, *Xp, *Hp, *Vp;
     double* coop_buf;      // exchange buffers of the cooperative launch (see k_fused_res)
     int* coop_cnt;         // [COOP_MAX_TILES] arrival counters, then one abort flag
     int coop_c;            // cooperating workgroups per frame tile chosen for this call (1 = off)
+    int all_c;             // k_fused_all: workgroups per frame tile (0 = that kernel is not used)
+    int n_cus;             // compute units of the device (sizes k_fused_all's persistent grid)
 };
 bool fused_supported(int M, int N, int T_, int dtype);
 FusedLayout fused_layout(int M, int N, int T_);

@@ -10,7 +10,9 @@ Orientation (`layout`):
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import threading
 from typing import Optional, Sequence
 
 import numpy as np
@@ -28,7 +30,12 @@ _STOPS = {"none": _lib.STOP_NONE, "sklearn": _lib.STOP_SKLEARN, "pymf": _lib.STO
 _LAYOUTS = {"frame_major": _lib.FRAME_MAJOR, "bin_major": _lib.BIN_MAJOR}
 _LOSSES = {"frobenius": _lib.LOSS_FROBENIUS, "kullback-leibler": _lib.LOSS_KL, "kl": _lib.LOSS_KL}
 
+# scratch memory handed to the C ABI, one buffer per (device, stream): include/evc.h promises that calls on
+# distinct streams are independent, so two streams (or two host threads on two streams) must never share
+# scratch.  A buffer belongs to the stream it was allocated on (torch's allocator is stream-ordered), so
+# growing it is safe: the old block is only reused by later work of the same stream.
 _workspaces = {}
+_ws_lock = threading.Lock()
 
 
 def _torch():
@@ -53,19 +60,32 @@ def require_device(device=None):
     return device
 
 
+class _Scratch:
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.buf = None
+
+
+@contextlib.contextmanager
 def _workspace(nbytes: int, device):
+    """The scratch buffer of (device, current stream), held for the duration of one native call."""
     torch = _torch()
-    key = (device.index,)
-    ws = _workspaces.get(key)
-    if ws is None or ws.numel() < nbytes:
-        _workspaces.pop(key, None)
-        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
-        _workspaces[key] = ws
-    return ws
+    key = (device.index, int(torch.cuda.current_stream(device).cuda_stream))
+    with _ws_lock:
+        slot = _workspaces.get(key)
+        if slot is None:
+            slot = _workspaces[key] = _Scratch()
+    with slot.lock:
+        if slot.buf is None or slot.buf.numel() < nbytes:
+            slot.buf = None
+            with torch.cuda.device(device):
+                slot.buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+        yield slot.buf
 
 
 def release_workspaces():
-    _workspaces.clear()
+    with _ws_lock:
+        _workspaces.clear()
 
 
 def _to_dev(x, tdtype, device):
@@ -146,7 +166,7 @@ def _solve(A, X, H0, B, *, layout="bin_major", iters=100, eps_mode="add", eps=No
            stop_rule="none", tol=0.0, utt_offsets: Optional[Sequence[int]] = None,
            dtype=None, device=None, info=False, out=None, loop_events=None,
            fused=True, fused_c=0, want_h=True, out_y=None, loss="frobenius", exact_div=False,
-           cooperative=True, _fake_coop_timeout=False):
+           cooperative=True, all_resident=True, _fake_coop_timeout=False):
     torch = _torch()
     device = require_device(device)
     L = _lib.lib()
@@ -212,22 +232,23 @@ def _solve(A, X, H0, B, *, layout="bin_major", iters=100, eps_mode="add", eps=No
     opts.loss = _LOSSES[loss]
     # knobs: bit 0 disables the fused persistent kernels; bit 1 asks for correctly rounded quotients in them;
     # bit 2 disables the cooperative launch used for one or two utterances; bits 8..15 = 1 or 2 force the
-    # general streamed kernel with that many frame tiles per workgroup (0 = automatic)
+    # general streamed kernel with that many frame tiles per workgroup (0 = automatic); bit 4 disables the
+    # all-resident kernel (k_fused_all: NT / 32 workgroups per frame tile, nothing streams)
     opts.reserved = ((0 if fused else 1) | (2 if exact_div else 0) | (0 if cooperative else 4)
-                     | (8 if _fake_coop_timeout else 0) | ((int(fused_c) & 0xff) << 8))
+                     | (8 if _fake_coop_timeout else 0) | (0 if all_resident else 16)
+                     | ((int(fused_c) & 0xff) << 8))
     if loop_events is not None:     # (torch.cuda.Event, torch.cuda.Event), already created
         opts.ev_loop_start = int(loop_events[0].cuda_event)
         opts.ev_loop_stop = int(loop_events[1].cuda_event)
 
     ws_bytes = int(L.evc_workspace_bytes(M, Mb, N, T, n_utt, dcode, opts.algo))
-    ws = _workspace(ws_bytes, device)
     n_slots = 1 + (iters // check_every if check_every > 0 else 0)
     n_iter = np.zeros(n_utt, dtype=np.int32) if info else None
     err = np.full((n_utt, n_slots), np.nan) if info else None
     ni_p = n_iter.ctypes.data_as(C.POINTER(C.c_int)) if info else None
     er_p = err.ctypes.data_as(C.POINTER(C.c_double)) if info else None
     h_ptr, h_ld = (H_d.data_ptr(), _ld(H_d)) if H_d is not None else (None, 0)
-    with torch.cuda.device(device):
+    with torch.cuda.device(device), _workspace(ws_bytes, device) as ws:
         stream = torch.cuda.current_stream(device).cuda_stream
         if B is None:
             st = L.evc_nmf_solve(
@@ -297,8 +318,7 @@ def frame_residuals(A, X, H, *, layout="bin_major", dtype=None, device=None):
         T = X_d.shape[0]
     err2 = torch.zeros(max(T, 1), dtype=torch.float64, device=device)
     ws_bytes = int(L.evc_workspace_bytes(M, 0, N, T, 1, dcode, _lib.ALGO_GRAM))
-    ws = _workspace(ws_bytes, device)
-    with torch.cuda.device(device):
+    with torch.cuda.device(device), _workspace(ws_bytes, device) as ws:
         stream = torch.cuda.current_stream(device).cuda_stream
         st = L.evc_residual(A_d.data_ptr(), _ld(A_d), X_d.data_ptr(), _ld(X_d), H_d.data_ptr(),
                             _ld(H_d), M, N, T, lay, dcode, err2.data_ptr(), ws.data_ptr(),
@@ -328,9 +348,8 @@ def griffin_lim(magnitude_spectrogram, fft_size, hopsamp, iterations, x0, *, dev
     ws_bytes = int(L.evc_griffin_lim_workspace_bytes(T, fft_size, hopsamp, iterations))
     if ws_bytes == 0:
         raise ValueError("unsupported Griffin-Lim configuration (fft_size must be even and >= 2)")
-    ws = _workspace(ws_bytes, device)
     rmse = np.zeros(max(iterations, 1)) if want_rmse else None
-    with torch.cuda.device(device):
+    with torch.cuda.device(device), _workspace(ws_bytes, device) as ws:
         stream = torch.cuda.current_stream(device).cuda_stream
         st = L.evc_griffin_lim(mag.data_ptr(), _ld(mag), T, fft_size, hopsamp, iterations, x.data_ptr(),
                                ws.data_ptr(), ws.numel(),
@@ -361,8 +380,8 @@ def stft(y, n_fft=400, hop_length=80, *, center=True, device=None):
     re = torch.empty(T, nb, dtype=torch.float64, device=device)
     im = torch.empty(T, nb, dtype=torch.float64, device=device)
     if T:
-        ws = _workspace(int(L.evc_stft_workspace_bytes(n, n_fft, hop_length, int(center))), device)
-        with torch.cuda.device(device):
+        with torch.cuda.device(device), \
+                _workspace(int(L.evc_stft_workspace_bytes(n, n_fft, hop_length, int(center))), device) as ws:
             stream = torch.cuda.current_stream(device).cuda_stream
             st = L.evc_stft(x.data_ptr(), n, n_fft, hop_length, int(center), re.data_ptr(), nb, im.data_ptr(), nb,
                             ws.data_ptr(), ws.numel(), C.c_void_p(stream))
@@ -393,13 +412,12 @@ def dtw_align(feats_a, feats_b, *, device=None, want_cost=False):
     ws_bytes = int(L.evc_dtw_workspace_bytes(ap, bp, n))
     if ws_bytes == 0:
         raise ValueError("utterance too long for the DTW kernel's wavefront buffers")
-    ws = _workspace(ws_bytes, device)
     cap = int(aoff[-1] + boff[-1])
     pa = torch.empty(max(cap, 1), dtype=torch.int32, device=device)
     pb = torch.empty(max(cap, 1), dtype=torch.int32, device=device)
     plen = torch.empty(n, dtype=torch.int32, device=device)
     tot = torch.empty(n, dtype=torch.float64, device=device)
-    with torch.cuda.device(device):
+    with torch.cuda.device(device), _workspace(ws_bytes, device) as ws:
         stream = torch.cuda.current_stream(device).cuda_stream
         st = L.evc_dtw_align(A.data_ptr(), D, ap, B.data_ptr(), D, bp, D, n, pa.data_ptr(), pb.data_ptr(),
                              plen.data_ptr(), tot.data_ptr(), ws.data_ptr(), ws.numel(), C.c_void_p(stream))
