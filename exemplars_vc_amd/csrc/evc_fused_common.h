@@ -139,6 +139,114 @@ __device__ __forceinline__ void mu_tile(HT& h, const f64x4& p, const f64x4& dacc
     }
 }
 
+// The same update split for software pipelining (k_fused_all): the quotients q = p / guard(d) of a tile.
+// mu_quot_fast is branch-free - it belongs to the basic block of the MFMAs it is interleaved with - and
+// returns whether every denominator of the lane allowed the fast path (its q is meaningless otherwise);
+// mu_quot_exact is the literal guard + IEEE division, taken by the whole wavefront when any lane needs it.
+// The update is then h <- h * q (divide first; for the ADD mode this differs from pymf's (h*p)/d in the last
+// bit only, like in k_fused_res).
+__device__ __forceinline__ bool mu_quot_fast(const f64x4& p, const f64x4& dacc, unsigned lo, double (&q)[4]) {
+    const unsigned span = FAST_HI_WORD > lo ? FAST_HI_WORD - lo : 0u;
+    const unsigned worst = max(max(hi_word(dacc[0]) - lo, hi_word(dacc[1]) - lo),
+                               max(hi_word(dacc[2]) - lo, hi_word(dacc[3]) - lo));
+    double rc[4];
+    batch_rcp(dacc, rc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) q[r] = p[r] * rc[r];
+    return worst < span;
+}
+// mu_quot_fast for two tiles at once, level by level: a dependent f64 VALU operation has ~28 cycles of latency
+// on gfx950 (throughput ~6), the quotient chain is 8 levels deep, and nothing else runs beside it (one wavefront
+// per SIMD, MFMAs do not overlap VALU) - so the second tile's chain fills the latency slots of the first.  The
+// compiler's scheduler does not model that latency and would emit one chain after the other; the fences keep
+// the levels apart.
+__device__ __forceinline__ bool mu_quot_fast2(const f64x4& pa, const f64x4& da, const f64x4& pb, const f64x4& db,
+                                              unsigned lo, double (&qa)[4], double (&qb)[4]) {
+#define EVC_LV __builtin_amdgcn_sched_barrier(0)
+    const unsigned span = FAST_HI_WORD > lo ? FAST_HI_WORD - lo : 0u;
+    const double a0 = da[0] * da[1], a1 = da[2] * da[3], b0 = db[0] * db[1], b1 = db[2] * db[3];
+    const unsigned wa = max(max(hi_word(da[0]) - lo, hi_word(da[1]) - lo), max(hi_word(da[2]) - lo, hi_word(da[3]) - lo));
+    const unsigned wb = max(max(hi_word(db[0]) - lo, hi_word(db[1]) - lo), max(hi_word(db[2]) - lo, hi_word(db[3]) - lo));
+    EVC_LV;
+    const double aa = a0 * a1, bb = b0 * b1;
+    EVC_LV;
+    double Ra = __builtin_amdgcn_rcp(aa), Rb = __builtin_amdgcn_rcp(bb);
+    EVC_LV;
+    const double ea = __builtin_fma(-aa, Ra, 1.0), eb = __builtin_fma(-bb, Rb, 1.0);
+    EVC_LV;
+    Ra = __builtin_fma(Ra, ea, Ra); Rb = __builtin_fma(Rb, eb, Rb);
+    EVC_LV;
+    const double Ra1 = Ra * a1, Rb1 = Rb * b1, Ra0 = Ra * a0, Rb0 = Rb * b0;
+    EVC_LV;
+    const double ra0 = Ra1 * da[1], rb0 = Rb1 * db[1], ra1 = Ra1 * da[0], rb1 = Rb1 * db[0];
+    const double ra2 = Ra0 * da[3], rb2 = Rb0 * db[3], ra3 = Ra0 * da[2], rb3 = Rb0 * db[2];
+    EVC_LV;
+    qa[0] = pa[0] * ra0; qb[0] = pb[0] * rb0; qa[1] = pa[1] * ra1; qb[1] = pb[1] * rb1;
+    qa[2] = pa[2] * ra2; qb[2] = pb[2] * rb2; qa[3] = pa[3] * ra3; qb[3] = pb[3] * rb3;
+    EVC_LV;
+#undef EVC_LV
+    return max(wa, wb) < span;
+}
+
+// mu_quot_fast with its VALU instructions placed by hand in the gaps of NM MFMAs (mf(i) issues the i-th).
+// The 23 instructions form a dependent chain of seven levels (range test + 2 products | product + v_rcp | fma |
+// fma | 2 | 4 | 4 multiplies): one level per gap, fenced by sched_barrier so that the compiler keeps the order -
+// every level's operands are ready when its gap comes round (an f64 MFMA takes 64 cycles), and neither the
+// wavefront nor the matrix pipe behind it ever waits on VALU latency.  (sched_group_barrier does not achieve
+// this placement: it counts instructions, it does not know the chain.)
+template <int NM, class F>
+__device__ __forceinline__ bool mu_quot_shadowed(F&& mf, const f64x4& p, const f64x4& d, unsigned lo,
+                                                 double (&q)[4]) {
+#define EVC_MF(i)                                                    \
+    do {                                                             \
+        if ((i) < NM) { mf(i); __builtin_amdgcn_sched_barrier(0); }  \
+    } while (0)
+#ifdef EVC_DBG_NOQ       // diagnostic (tools/ubench): the MFMAs alone, no quotient arithmetic
+    for (int i = 0; i < NM; ++i) mf(i);
+    for (int r = 0; r < 4; ++r) q[r] = p[r];
+    return true;
+#endif
+    EVC_MF(0);
+    const unsigned span = FAST_HI_WORD > lo ? FAST_HI_WORD - lo : 0u;
+    const unsigned worst = max(max(hi_word(d[0]) - lo, hi_word(d[1]) - lo),
+                               max(hi_word(d[2]) - lo, hi_word(d[3]) - lo));
+    const double a = d[0] * d[1], b = d[2] * d[3];
+    __builtin_amdgcn_sched_barrier(0);
+    EVC_MF(1);
+    const double ab = a * b;
+    double R = __builtin_amdgcn_rcp(ab);
+    __builtin_amdgcn_sched_barrier(0);
+    EVC_MF(2);
+    const double e = __builtin_fma(-ab, R, 1.0);
+    __builtin_amdgcn_sched_barrier(0);
+    EVC_MF(3);
+    R = __builtin_fma(R, e, R);
+    __builtin_amdgcn_sched_barrier(0);
+    EVC_MF(4);
+    const double Ra = R * b, Rb = R * a;
+    __builtin_amdgcn_sched_barrier(0);
+    EVC_MF(5);
+    const double r0 = Ra * d[1], r1 = Ra * d[0], r2 = Rb * d[3], r3 = Rb * d[2];
+    __builtin_amdgcn_sched_barrier(0);
+    EVC_MF(6);
+    q[0] = p[0] * r0; q[1] = p[1] * r1; q[2] = p[2] * r2; q[3] = p[3] * r3;
+    __builtin_amdgcn_sched_barrier(0);
+    EVC_MF(7);
+#undef EVC_MF
+    static_assert(NM <= 8, "at most 8 MFMAs per shadow");
+    return worst < span;
+}
+__device__ __forceinline__ void mu_quot_exact(const f64x4& p, const f64x4& dacc, int mode, double eps,
+                                              double (&q)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        double dn = dacc[r];
+        dn = (mode == EVC_EPS_ZERO_REPLACE && dn == 0.0) ? eps : dn;   // sklearn _nmf.py:620
+        dn = (mode == EVC_EPS_CLAMP && !(dn > eps)) ? eps : dn;         // deComP
+        q[r] = p[r] / dn;
+    }
+}
+
 hipError_t fused_res_launch(int msteps, const FusedArgs& a, hipStream_t s);
 // evc_fused_all.hip: every activation and numerator tile register-resident, NT / 32 workgroups per frame tile
 hipError_t fused_all_launch(int msteps, const FusedArgs& a, int n_cus, hipStream_t s);

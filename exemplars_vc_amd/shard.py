@@ -32,25 +32,32 @@ def partition_utterances(lengths: Sequence[int], n_shards: int) -> List[List[int
 
 
 def convert_utterances(X_list, A, B, *, iters=100, tol=0.0, eps_mode="zero_replace",
-                       init="sklearn", algo="auto", device=None, solver: Optional[Callable] = None):
+                       init="sklearn", algo="auto", device=None, solver: Optional[Callable] = None,
+                       info=False):
     """Convert a list of utterances (each T_u x M, frames as rows) with dictionary A (N x M)
     and target dictionary B (N x Mb): one batched solve + one synthesis.
-    Returns a list of (T_u x Mb) arrays.  `solver(X_cat, offsets)` -> (T x N) activations can
-    be injected by tests; the default is the HIP path."""
+    Returns a list of (T_u x Mb) arrays; with info=True a list of (Y_u, n_iter_u) pairs (n_iter_u: the
+    updates applied to utterance u - the per-call `n_iter` of the reference's scikit-learn call).
+    `solver(X_cat, offsets)` -> (T x N) activations can be injected by tests; the default is the HIP path."""
     if not X_list:
         return []
     offs = np.concatenate([[0], np.cumsum([len(x) for x in X_list])]).astype(np.int32)
     X = np.concatenate([np.asarray(x) for x in X_list], axis=0)
+    n_iter = None
     if solver is None:
         from .solver import convert
-        Y = convert(A, X, B, want_h=False, layout="frame_major", iters=iters, eps_mode=eps_mode,
-                    init=init, algo=algo, utt_offsets=offs, device=device,
-                    check_every=10 if tol > 0 else 0,
-                    stop_rule="sklearn" if tol > 0 else "none", tol=tol)
+        out = convert(A, X, B, want_h=False, layout="frame_major", iters=iters, eps_mode=eps_mode,
+                      init=init, algo=algo, utt_offsets=offs, device=device,
+                      check_every=10 if tol > 0 else 0,
+                      stop_rule="sklearn" if tol > 0 else "none", tol=tol, info=info)
+        Y, n_iter = (out[0], out[1]["n_iter"]) if info else (out, None)
     else:
         act = solver(X, offs)
         Y = act @ np.asarray(B)
-    return [Y[offs[i]:offs[i + 1]] for i in range(len(X_list))]
+    Ys = [Y[offs[i]:offs[i + 1]] for i in range(len(X_list))]
+    if info:
+        return [(y, int(n_iter[i]) if n_iter is not None else -1) for i, y in enumerate(Ys)]
+    return Ys
 
 
 def convert_sharded(X_list, A, B, *, rank=None, world_size=None, gather=True, **kw):
