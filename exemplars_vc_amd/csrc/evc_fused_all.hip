@@ -60,39 +60,24 @@ constexpr unsigned ALL_POLL_LIMIT = 1u << 17;
 #define EVC_STAMP(i)
 #endif
 
-// dynamic LDS of k_fused_all<MSTEPS, .>: the D-product fragments of the member's tiles when they fit beside
-// the exchange state (MSTEPS <= 7, i.e. M <= 28: 112 KiB + 42 KiB of the CU's 160 KiB)
-template <int MSTEPS> struct AllLds {
-    static constexpr size_t state_bytes = (size_t)(2 * AW + 4) * MSTEPS * 64 * sizeof(double) + 16;
-    static constexpr size_t a1_full = (size_t)ATILES * MSTEPS * 64 * sizeof(double);
-    static constexpr bool A1 = a1_full + state_bytes <= 160 * 1024;
-    static constexpr size_t a1_bytes = A1 ? a1_full : 0;
-    static constexpr size_t bytes = a1_bytes + state_bytes;
-};
-
-// DZERO: the denominator accumulators start at the inline constant 0 (l1 == 0 and no additive eps: the reference
-// script's case) instead of at a value held in 8 VGPRs.
-template <int MSTEPS, int C, bool DZERO>
+template <int MSTEPS, int C>
 __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
     constexpr int MT = MSTEPS > 4 ? 2 : 1;
-    constexpr int NE = MSTEPS * 64;              // elements of V (accumulator order = B-operand order)
+    constexpr int E = MT * 4 * 64;               // stride of one V image (accumulator order)
+    constexpr int NE = MSTEPS * 64;              // elements of V actually used
     constexpr int MSP = (MSTEPS + 1) & ~1;       // k-steps padded to pairs in A1p
-    typedef AllLds<MSTEPS> L;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double* const s_a1 = reinterpret_cast<double*>(smem);                 // [ATILES][MSTEPS * 64] (L::A1)
-    double* const s_red = reinterpret_cast<double*>(smem + L::a1_bytes);  // [2][AW][NE] partial V' per wavefront
-    double* const s_v = s_red + 2 * AW * NE;                              // [2][NE] V, B-operand order
-    double* const s_sum = s_v + 2 * NE;                                   // [2][NE] the member's partial V'
-    unsigned* const s_cnt = reinterpret_cast<unsigned*>(s_sum + 2 * NE);  // [2] wavefronts that have delivered
-    int* const s_fail = reinterpret_cast<int*>(s_cnt + 2);
+    __shared__ double s_red[2][AW * E];          // partial V' of every wavefront, per half
+    __shared__ double s_v[2][E];                 // V, B-operand order
+    __shared__ double s_x[2][E];                 // X, B-operand order
+    __shared__ int s_fail;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = w8 >> 2, w = w8 & 3, th = tid & (AW * 64 - 1);
     const int member = blockIdx.x % C;
     const int g = 2 * (blockIdx.x / C) + half;           // the group this half is a member of
-    double* const red = s_red + half * (AW * NE);
-    double* const vL = s_v + half * NE;
-    double* const sumL = s_sum + half * NE;
+    double* const red = s_red[half];
+    double* const vL = s_v[half];
+    double* const xL = s_x[half];
     const double* __restrict__ A1p = a.A1p;
     const double* __restrict__ A2p = a.A2p;
     f64x2* __restrict__ Hp = a.Hp;
@@ -104,30 +89,7 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
     // hoisted out of the loops as per-lane 64-bit addresses (32 VGPRs).
     long sw = 0;
 
-    // The D-product fragments of the member's 32 tiles live in LDS for the whole launch when they fit (both
-    // halves of the workgroup are the same member of their groups, so they share them): with one wavefront per
-    // SIMD sweeping, nobody covers an L2 round trip (measured: 1540 cycles per unit against 960 of MFMAs with
-    // both fragment sets streamed from L2).  Per tile: MSTEPS/2 blocks of [lane][2 k-steps] + one [lane] block.
-    if (L::A1) {
-        constexpr int PAIRS = MSTEPS / 2, TS = MSTEPS * 64;
-        const double* src = A1p + (long)member * ATILES * (MSP * 64);
-        for (int i = tid; i < ATILES * TS; i += ATHREADS) {
-            const int t = i / TS, r = i % TS;
-            s_a1[i] = src[t * (MSP * 64) + (r < PAIRS * 128 ? r : PAIRS * 128 + 2 * (r - PAIRS * 128))];
-        }
-    }
     auto load_a1 = [&](double (&a1)[MSTEPS], int k) {
-        if (L::A1) {
-            const double* t = s_a1 + (w + AW * k) * (MSTEPS * 64);
-#pragma unroll
-            for (int s = 0; s + 1 < MSTEPS; s += 2) {
-                const f64x2 v = reinterpret_cast<const f64x2*>(t)[(s >> 1) * 64 + lane];
-                a1[s] = v[0];
-                a1[s + 1] = v[1];
-            }
-            if (MSTEPS & 1) a1[MSTEPS - 1] = t[(MSTEPS / 2) * 128 + lane];
-            return;
-        }
         const f64x2* t = reinterpret_cast<const f64x2*>(A1p + (tile0 + sw + AW * k) * (MSP * 64));
 #pragma unroll
         for (int s = 0; s < MSTEPS; s += 2) {
@@ -141,9 +103,6 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
         }
     };
     auto load_a2 = [&](double (&a2)[MT][4], int k) {
-#ifdef EVC_DBG_NOA2      // diagnostic (tools/ubench): no fragment loads inside the sweep
-        if (k > 0) return;
-#endif
         const f64x2* t = reinterpret_cast<const f64x2*>(A2p + (tile0 + sw + AW * k) * (MT * 256));
 #pragma unroll
         for (int u = 0; u < MT; ++u)
@@ -157,11 +116,11 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
 
     const int mode = a.eps_mode;
     const double eps = a.eps;
-    const double d0 = DZERO ? 0.0 : a.l1 + (mode == EVC_EPS_ADD ? a.eps : 0.0);
+    const double d0 = a.l1 + (mode == EVC_EPS_ADD ? a.eps : 0.0);
     const f64x4 dinit = {d0, d0, d0, d0};
     const unsigned lo = fast_lo(mode, eps);
     unsigned seq = 0;                            // exchanges done by this half's group so far
-    if (tid == 0) { *s_fail = 0; s_cnt[0] = 0; s_cnt[1] = 0; }
+    if (tid == 0) s_fail = 0;
 
     for (long tt0 = g - half; tt0 < a.TT; tt0 += a.groups) {     // half 0's tile decides (it has the lower index)
         const long tt = tt0 + half;
@@ -181,7 +140,12 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
         f64x4 p[AKT];
         double a1[MSTEPS], a2[MT][4];
         if (valid) {
-            for (int e = th; e < NE; e += AW * 64) vL[e] = a.Vp[(tt * 8 + (e >> 6)) * 64 + (e & 63)];
+            for (int e = th; e < E; e += AW * 64) {
+                const int s = e >> 6, l = e & 63;
+                const bool in = s < MSTEPS;
+                xL[e] = in ? a.Xp[(tt * MSTEPS + s) * 64 + l] : 0.0;
+                vL[e] = in ? a.Vp[(tt * 8 + s) * 64 + l] : 0.0;
+            }
 #pragma unroll
             for (int k = 0; k < AKT; ++k) {
                 const f64x2* t = Hp + (tt * NT + tile0 + AW * k) * 128;
@@ -193,7 +157,7 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
         if (valid) {                             // numerator tiles, once per frame tile
             double x[MSTEPS];
 #pragma unroll
-            for (int s = 0; s < MSTEPS; ++s) x[s] = a.Xp[(tt * MSTEPS + s) * 64 + lane];
+            for (int s = 0; s < MSTEPS; ++s) x[s] = xL[s * 64 + lane];
             load_a1(a1, 0);
 #pragma unroll
             for (int k = 0; k < AKT; ++k) {
@@ -211,114 +175,50 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
             if (valid && mine && step < 2 * a.iters) {
                 // ---------------- sweep: h <- h p / (A_j^T V), V' += A_j h over the 8 resident tiles
                 asm volatile("" : "+s"(sw));
-                f64x4 vn[MT];
-#pragma unroll
-                for (int u = 0; u < MT; ++u) vn[u] = f64x4{0, 0, 0, 0};
-                // One wavefront owns its SIMD during a sweep, so nothing covers its stalls, and on gfx950 an f64
-                // MFMA and VALU instructions do not overlap.  Measured on this sweep (tools/ubench/fused_all_bench.hip;
-                // the 15 MFMAs of a unit alone: 915 cycles): with the update arithmetic of ONE tile between D_k and
-                // V'_k: +550..600 cycles, wherever its 27 instructions are placed (one clump, or level by level in
-                // the gaps between the MFMAs): the quotient chain is 9 dependent f64 operations deep and a dependent
-                // f64 VALU operation has ~28 cycles of latency (throughput ~6), which nothing else fills.  So the
-                // sweep works on PAIRS of tiles: D_a, D_b (14 MFMAs), then the two tiles' update chains together
-                // (independent: the latency slots of one are the issue slots of the other), then V'_a, V'_b.
-                // D fragments come from LDS (s_a1), refilled pair of k-steps by pair of k-steps behind the MFMAs that
-                // consume them; V' fragments are double-buffered and requested one pair (~2000 cycles) ahead.
                 double v[MSTEPS];
 #pragma unroll
                 for (int s = 0; s < MSTEPS; ++s) v[s] = vL[s * 64 + lane];
-                // d = A_k^T V with a1 = fragments of tile k; a1 is refilled with tile kn's behind each MFMA pair
-                auto dchain = [&](f64x4& d, int kn) {
-                    const double* t = s_a1 + (w + AW * kn) * (MSTEPS * 64);
+                f64x4 vn[MT];
 #pragma unroll
-                    for (int s = 0; s < MSTEPS; s += 2) {
-                        d = Mma<double>::mma(a1[s], v[s], d);
-                        if (s + 1 < MSTEPS) d = Mma<double>::mma(a1[s + 1], v[s + 1], d);
-                        if (L::A1) {
-                            if (s + 1 < MSTEPS) {
-                                const f64x2 f = reinterpret_cast<const f64x2*>(t)[(s >> 1) * 64 + lane];
-                                a1[s] = f[0];
-                                a1[s + 1] = f[1];
-                            } else {
-                                a1[s] = t[(MSTEPS / 2) * 128 + lane];
-                            }
-                        }
-                    }
-                    if (!L::A1) load_a1(a1, kn);
-                };
-                auto vchain = [&](const double (&aa)[MT][4], const HTile& hh) {
+                for (int u = 0; u < MT; ++u) vn[u] = f64x4{0, 0, 0, 0};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int u = 0; u < MT; ++u) vn[u] = Mma<double>::mma(aa[u][r], hh[r], vn[u]);
-                };
-                double a2b[MT][4];                   // second V'-fragment buffer (a2: even units, a2b: odd units)
-                load_a2(a2, 0);
-                load_a2(a2b, 1);
-                static_assert(AKT % 2 == 0, "the sweep works on pairs of tiles");
-#pragma unroll
-                for (int k = 0; k < AKT; k += 2) {
+                for (int k = 0; k < AKT; ++k) {
                     __builtin_amdgcn_sched_barrier(0);
-                    f64x4 da = dinit, db = dinit;
-                    dchain(da, k + 1);               // a1 holds tile k on entry (fetched behind the previous chain)
-                    dchain(db, (k + 2) % AKT);       // (k = 6: tile 0, for the next sweep's first chain)
-                    __builtin_amdgcn_sched_barrier(0);
-                    double qa[4], qb[4];
-                    const bool fab = mu_quot_fast2(p[k], da, p[k + 1], db, lo, qa, qb);
-                    // (pinned: the optimiser would otherwise sink the quotients behind the rare-path branch)
+                    load_a2(a2, k);
+                    f64x4 d = dinit;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { asm volatile("" : "+v"(qa[r])); asm volatile("" : "+v"(qb[r])); }
-                    if (!__all(fab)) {
-                        mu_quot_exact(p[k], da, mode, eps, qa);
-                        mu_quot_exact(p[k + 1], db, mode, eps, qb);
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { h[k][r] *= qa[r]; h[k + 1][r] *= qb[r]; }
+                    for (int s = 0; s < MSTEPS; ++s) d = Mma<double>::mma(a1[s], v[s], d);
+                    load_a1(a1, (k + 1) % AKT);      // the next unit's (or the next sweep's first) fragments
                     __builtin_amdgcn_sched_barrier(0);
-                    vchain(a2, h[k]);
-                    if (k + 2 < AKT) load_a2(a2, k + 2);
-                    vchain(a2b, h[k + 1]);
-                    if (k + 2 < AKT) load_a2(a2b, k + 3);
+                    mu_tile<false>(h[k], p[k], d, mode, eps, lo);
+#pragma unroll
+                    for (int u = 0; u < MT; ++u)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) vn[u] = Mma<double>::mma(a2[u][r], h[k][r], vn[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < MT; ++u)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (u * 4 + r < MSTEPS) red[w * NE + (u * 4 + r) * 64 + lane] = vn[u][r];
-                // The wavefront that delivers last sums the four partials (fixed order) and publishes the member's
-                // partial V' at once: the words travel to the peers while this half is still on its way to the
-                // step barrier, so the exchange step that follows normally finds them all there.
-                unsigned arrived = 0;
-                if (lane == 0)
-                    arrived = __hip_atomic_fetch_add(&s_cnt[half], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-                arrived = __builtin_amdgcn_readfirstlane(arrived);
-                if ((arrived & (AW - 1)) == AW - 1) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    long long* xb = reinterpret_cast<long long*>(a.coop_buf) +
-                                    ((size_t)(seq & 1) * a.groups + g) * (size_t)(C * 512) + member * 512;
-                    const long long tag = (seq >> 1) & 1;        // a buffer is reused every second exchange
-#pragma unroll
-                    for (int e = lane; e < NE; e += 64) {
-                        double acc = 0.0;
-#pragma unroll
-                        for (int ww = 0; ww < AW; ++ww) acc += red[ww * NE + e];
-                        sumL[e] = acc;
-                        if (C > 1)
-                            __hip_atomic_store(xb + e, (__double_as_longlong(acc) & ~1LL) | tag, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                }
+                        if (u * 4 + r < MSTEPS) red[w * E + (u * 4 + r) * 64 + lane] = vn[u][r];
             } else if (valid && !mine && step > 0) {
-                // ---------------- exchange: V' = sum over the members, no barrier inside
+                // ---------------- exchange: V' = sum over wavefronts and members, no barrier inside
                 const int e0 = th, e1 = th + AW * 64;
                 const bool has1 = e1 < NE;
-                double s0 = sumL[e0], s1 = sumL[has1 ? e1 : e0];
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int ww = 0; ww < AW; ++ww) {
+                    s0 += red[ww * E + e0];
+                    s1 += red[ww * E + (has1 ? e1 : e0)];
+                }
                 if (C > 1) {
                     long long* xb = reinterpret_cast<long long*>(a.coop_buf) +
                                     ((size_t)(seq & 1) * a.groups + g) * (size_t)(C * 512);
-                    const long long tag = (seq >> 1) & 1;
+                    const long long tag = (seq >> 1) & 1;        // a buffer is reused every second exchange
                     const long long m0 = (__double_as_longlong(s0) & ~1LL) | tag;
                     const long long m1 = (__double_as_longlong(s1) & ~1LL) | tag;
+                    __hip_atomic_store(xb + member * 512 + e0, m0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (has1) __hip_atomic_store(xb + member * 512 + e1, m1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     bool ok = true;
                     unsigned polls = 0;
                     {   // watch one word per peer (lane m <-> member m): C - 1 loads per poll and wavefront
@@ -370,7 +270,7 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
                         s1 += __longlong_as_double(b1[m] & ~1LL);
                     }
                     ++seq;
-                    if (!ok) *s_fail = 1;
+                    if (!ok) s_fail = 1;
                 }
                 vL[e0] = s0;
                 if (has1) vL[e1] = s1;
@@ -378,7 +278,7 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
             EVC_STAMP(1);
             __syncthreads();
             EVC_STAMP(2);
-            if (C > 1 && *s_fail) {               // a peer never showed up: void the launch, let everybody leave
+            if (C > 1 && s_fail) {               // a peer never showed up: void the launch, let everybody leave
                 if (tid == 0) __hip_atomic_store(a.coop_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return;
             }
@@ -398,7 +298,7 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
                     double e = 0.0;
 #pragma unroll
                     for (int s = 0; s < MSTEPS; ++s) {
-                        const double x = a.Xp[(tt * MSTEPS + s) * 64 + lane], vv = vL[s * 64 + lane];
+                        const double x = xL[s * 64 + lane], vv = vL[s * 64 + lane];
                         e += (x - vv) * (x - vv);
                     }
                     e += __shfl_xor(e, 16, 64);  // the 4 lane groups hold one frame's bins
@@ -408,21 +308,14 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
                 }
             }
         }
-        __syncthreads();                         // vL is rewritten for the next frame tile
+        __syncthreads();                         // xL / vL are rewritten for the next frame tile
     }
 }
 
-template <int MSTEPS, int C, bool DZERO>
-static hipError_t launch_all_z(FusedArgs a, int n_cus, hipStream_t s) {
-    const size_t lds = AllLds<MSTEPS>::bytes;
-    hipError_t e = hipSuccess;
-    if (lds > 64 * 1024) {   // per launch: no mutable global state is kept
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_all<MSTEPS, C, DZERO>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
+template <int MSTEPS, int C>
+static hipError_t launch_all(FusedArgs a, int n_cus, hipStream_t s) {
     int occ = 0;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fused_all<MSTEPS, C, DZERO>, ATHREADS, lds);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fused_all<MSTEPS, C>, ATHREADS, 0);
     if (e != hipSuccess) return e;
     if (occ < 1) return hipErrorInvalidValue;
     long resident = n_cus;                       // one workgroup (two members) per CU
@@ -437,14 +330,8 @@ static hipError_t launch_all_z(FusedArgs a, int n_cus, hipStream_t s) {
         e = hipMemsetAsync(a.coop_buf, 0xFF, sizeof(double) * 2 * (size_t)a.groups * C * 512, s);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_fused_all<MSTEPS, C, DZERO>), dim3((unsigned)(pairs * C)), dim3(ATHREADS), lds, s, a);
+    hipLaunchKernelGGL((k_fused_all<MSTEPS, C>), dim3((unsigned)(pairs * C)), dim3(ATHREADS), 0, s, a);
     return hipGetLastError();
-}
-
-template <int MSTEPS, int C>
-static hipError_t launch_all(const FusedArgs& a, int n_cus, hipStream_t s) {
-    const double d0 = a.l1 + (a.eps_mode == EVC_EPS_ADD ? a.eps : 0.0);
-    return d0 == 0.0 ? launch_all_z<MSTEPS, C, true>(a, n_cus, s) : launch_all_z<MSTEPS, C, false>(a, n_cus, s);
 }
 
 template <int MSTEPS>
