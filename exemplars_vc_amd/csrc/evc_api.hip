@@ -74,7 +74,10 @@ Workspace<T> carve(void* base, const Dims& d, int algo, int n_slots, bool fused)
     w.H0 = need_h0 ? c.take<T>((size_t)d.Tp * d.Np) : nullptr;
     w.Pt = fused ? nullptr : c.take<T>((size_t)d.Tp * d.Np);
     w.Vt = fused ? nullptr : c.take<T>((size_t)d.Tp * d.Mj);
-    w.vsplit_elems = (!fused && d.Tp <= 2048) ? (size_t)8 * d.Tp * d.Mj : 0;
+    // slabs for the split-K form of V = H Am^T: its T x Mj output has few tiles (Mj is 64..576) against a long
+    // contraction (N), so short batches need the split to fill the CUs
+    const int vslabs = d.Tp <= 2048 ? 32 : (d.Tp <= 16384 ? 4 : (d.Tp <= 65536 ? 2 : 0));
+    w.vsplit_elems = fused ? 0 : (size_t)vslabs * d.Tp * d.Mj;
     w.Vsplit = w.vsplit_elems ? c.take<T>(w.vsplit_elems) : nullptr;
     w.fl = FusedLayout{};
     w.fb = FusedBuffers{};

@@ -16,6 +16,8 @@
 // group of the MFMA result writes one 128-byte (f64) segment.
 #include "evc_internal.h"
 
+#include <stdlib.h>
+
 namespace evc {
 
 constexpr int KS = 16;  // k-slab depth staged per barrier
@@ -171,10 +173,30 @@ __global__ __launch_bounds__(256) void k_sum_slabs(const T* __restrict__ part, l
 }
 
 template <typename T>
+hipError_t sum_slabs(const T* part, long slab, int splits, T* C, hipStream_t s) {
+    hipLaunchKernelGGL((k_sum_slabs<T>), dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, s, part, slab, splits,
+                       slab, C);
+    return hipGetLastError();
+}
+
+// EVC_GEMM_V1=1 in the environment keeps every contraction on k_gemm_nt (A/B timing of the two generations)
+static bool use_gemm2() {
+    static const bool v1 = getenv("EVC_GEMM_V1") != nullptr;
+    return !v1;
+}
+
+template <typename T>
 hipError_t gemm_nt(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int I, int J, int Kd,
                    hipStream_t s, T* scratch, size_t scratch_elems, int* splits_out) {
     if (splits_out) *splits_out = 0;
     if (I <= 0 || J <= 0) return hipSuccess;
+    if (use_gemm2() && gemm2_ok<T>(L, ldl, R, ldr, C, ldc, I, J, Kd)) {
+        int dev = 0, cus = 0;
+        if (scratch && (hipGetDevice(&dev) != hipSuccess ||
+                        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess))
+            cus = 0;
+        return gemm2<T>(L, ldl, R, ldr, C, ldc, I, J, Kd, s, scratch, scratch_elems, splits_out, cus);
+    }
     if (I % 128 || J % 64 || Kd % KS || Kd <= 0) return hipErrorInvalidValue;
     MuEpilogue<T> ep{};
     // few output tiles (one utterance): 64x64 tiles put 2-4x more workgroups on the 256 CUs, and a long
@@ -212,6 +234,9 @@ hipError_t gemm_nt_mu(const T* L, int ldl, const T* R, int ldr, T* Hout, int I, 
                       const MuEpilogue<T>& ep, hipStream_t s) {
     if (I <= 0 || J <= 0) return hipSuccess;
     if (I % 128 || J % 128 || Kd % KS || Kd <= 0) return hipErrorInvalidValue;
+    if (use_gemm2() && gemm2_ok<T>(L, ldl, R, ldr, Hout, ep.ldh, I, J, Kd) &&
+        gemm2_ok<T>(ep.Hin, ep.ldh, ep.Hin, ep.ldh, ep.kl ? ep.Hin : ep.P, ep.ldh, I, J, Kd))
+        return gemm2_mu<T>(L, ldl, R, ldr, Hout, I, J, Kd, ep, s);
     // Tile quantisation for one or two utterances: 128x128 tiles run in rounds of 256 (one per CU), 64x128
     // tiles in rounds of 512 (two per CU, half the work each; a trailing all-padding row tile leaves at
     // once).  C3 (768 x 8192): 384 full tiles = 2 rounds against 768 half tiles = 2 half rounds.
@@ -395,6 +420,7 @@ hipError_t synth_skinny(const T* H, long hst, long hsn, const T* B, long bsn, lo
     template hipError_t gemm_nt<T>(const T*, int, const T*, int, T*, int, int, int, int, hipStream_t, T*, size_t, int*); \
     template hipError_t gemm_nt_mu<T>(const T*, int, const T*, int, T*, int, int, int,                \
                                       const MuEpilogue<T>&, hipStream_t);                            \
+    template hipError_t sum_slabs<T>(const T*, long, int, T*, hipStream_t);                          \
     template hipError_t gemm_strided<T>(const T*, long, long, const T*, long, long, T*, long, long,  \
                                         int, int, int, hipStream_t);                                  \
     template hipError_t synth_skinny<T>(const T*, long, long, const T*, long, long, T*, long, long,  \

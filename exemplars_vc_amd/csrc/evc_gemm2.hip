@@ -1,0 +1,318 @@
+// k_gemm2: the contractions of the generic path (M > 32 bins, float32, GRAM / LITERAL), second generation.
+//
+//   C[f][r] = sum_k L[f][k] R[r][k]          L: frames x K, R: rows (exemplars or bins) x K, both k-contiguous
+//
+// What k_gemm_nt (evc_gemm.hip) left on the table, by its profile (profiles/r02_base_*: 44-63 % matrix-pipe
+// occupancy, one LDS bank conflict per LDS instruction at float32):
+//   * k-major LDS with one scalar ds_read per operand and k-step -> here the LDS image is row-major with the
+//     row's 16-byte slots XOR-swizzled by the row number, every fragment read is a conflict-free ds_read_b128
+//     that feeds 2 (f64) or 4 (f32) k-steps (the MFMA's k assignment is free as long as both operands use
+//     the same one: lane group q takes the k-values of slot 4 kk + q);
+//   * k-slabs of 16 with a barrier each -> slabs of 128 or 256 bytes per row, one barrier per slab;
+//   * 4 scalar loads/stores per accumulator tile in the update epilogue -> the operand roles are swapped (rows
+//     of R on the MFMA's i axis, frames on j) and, for f64, the rows of a 16-tile are permuted on the way out
+//     of LDS, so that a lane's four results are four CONSECUTIVE columns of one frame row: H, P and H' move as
+//     one 16- or 32-byte access per lane and tile;
+//   * a single tile shape and no look at how the grid fills 256 CUs -> shapes and split-K chosen per call.
+#include "evc_internal.h"
+
+namespace evc {
+
+template <typename T> struct G2T;
+template <> struct G2T<double> { typedef double vec __attribute__((ext_vector_type(2))); typedef double vec4 __attribute__((ext_vector_type(4))); };
+template <> struct G2T<float> { typedef float vec __attribute__((ext_vector_type(4))); typedef float vec4 __attribute__((ext_vector_type(4))); };
+
+// BF x BR block (frames x rows of R), WF x WR per wavefront, BK elements of k per slab, MINW: waves per SIMD the
+// register allocation is held to (2 workgroups per CU when the LDS image is 64 KiB)
+template <typename T, int BF, int BR, int WF, int WR, int BK, bool MU, int MINW>
+__global__ __launch_bounds__((BF / WF) * (BR / WR) * 64, MINW) void k_gemm2(
+    const T* __restrict__ L, int ldl, const T* __restrict__ R, int ldr, T* __restrict__ C, int ldc, int Kd,
+    MuEpilogue<T> ep, long slab) {
+    typedef typename Mma<T>::acc_t acc_t;
+    typedef typename G2T<T>::vec vec;
+    typedef typename G2T<T>::vec4 vec4;
+    constexpr int EPV = 16 / (int)sizeof(T);             // elements per 16-byte slot
+    constexpr int SLOTS = BK / EPV;                       // slots per LDS row (8 or 16)
+    constexpr int NWF = BF / WF, NWR = BR / WR, NTHR = NWF * NWR * 64;
+    constexpr int FI = WF / 16, RI = WR / 16;
+    constexpr int ROWS = BF + BR;
+    constexpr int RPP = NTHR / SLOTS;                     // rows staged per pass of the workgroup
+    constexpr int PL = BF / RPP, PR = BR / RPP;           // passes over the L rows / the R rows
+    constexpr int KK = SLOTS / 4;                         // fragment reads per slab and operand tile
+    static_assert(SLOTS == 8 || SLOTS == 16, "LDS rows of 128 or 256 bytes");
+    static_assert(NTHR % SLOTS == 0 && RPP % SLOTS == 0 && BF % RPP == 0 && BR % RPP == 0, "staging shape");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    T* sm = reinterpret_cast<T*>(smem_raw);               // [2][ROWS][BK]
+
+    // split-K: blockIdx.z owns k in [z Kd, (z+1) Kd) and writes its partial product to slab z
+    L += (long)blockIdx.z * Kd;
+    R += (long)blockIdx.z * Kd;
+    C += (long)blockIdx.z * slab;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wf = w % NWF, wr = w / NWF;
+    const int i16 = lane & 15, q = lane >> 4;
+    const long bf0 = (long)blockIdx.y * BF, br0 = (long)blockIdx.x * BR;
+
+    if (MU) {
+        // a block whose frames all belong to stopped utterances only carries H over
+        int any = 0;
+        if (tid < BF) {
+            const int u = ep.frame_utt[bf0 + tid];
+            any = (u >= 0) && (ep.active[u] != 0);
+        }
+        if (!__syncthreads_or(any)) {
+            if (C != ep.Hin) {
+                for (int e = tid; e < BF * BR; e += NTHR) {
+                    const long r = bf0 + e / BR, c = br0 + e % BR;
+                    C[r * ldc + c] = ep.Hin[r * ep.ldh + c];
+                }
+            }
+            return;
+        }
+    }
+
+    // staging: thread -> (row0 + pass * RPP, slot); the swizzled slot is the same in every pass (RPP % SLOTS == 0)
+    const int row0 = tid / SLOTS, slot = tid % SLOTS;
+    // swizzle keys.  L rows (frames): the row number.  R rows: the MFMA row i that reads the row - for f64 the
+    // rows of a 16-tile are permuted on the way out (see `ar` below), and with 128-byte rows two LDS rows share
+    // one bank row, so the key is made of the bits of i that keep the 16 lanes of a ds_read_b128 group apart
+    auto key_of = [](int i) { return SLOTS == 16 ? i : ((i & 3) | ((i >> 3) << 2)); };
+    const int r15 = row0 & 15;
+    const int pslot = slot ^ (row0 & (SLOTS - 1));
+    const int pslotR = sizeof(T) == 8 ? slot ^ key_of(4 * (r15 & 3) + (r15 >> 2)) : pslot;
+    const T* gl = L + (bf0 + row0) * (long)ldl + slot * EPV;
+    const T* gr = R + (br0 + row0) * (long)ldr + slot * EPV;
+    vec stg[PL + PR];
+    auto fetch = [&](int k0) {
+        const bool in = k0 + slot * EPV < Kd;             // (Kd is a multiple of 16 elements: a slot is all in or all out)
+#pragma unroll
+        for (int i = 0; i < PL; ++i)
+            stg[i] = in ? *reinterpret_cast<const vec*>(gl + (long)i * RPP * ldl + k0) : vec(0);
+#pragma unroll
+        for (int i = 0; i < PR; ++i)
+            stg[PL + i] = in ? *reinterpret_cast<const vec*>(gr + (long)i * RPP * ldr + k0) : vec(0);
+    };
+    auto stash = [&](int buf) {
+        T* b = sm + buf * (ROWS * BK);
+#pragma unroll
+        for (int i = 0; i < PL; ++i) *reinterpret_cast<vec*>(b + (row0 + i * RPP) * BK + pslot * EPV) = stg[i];
+#pragma unroll
+        for (int i = 0; i < PR; ++i) *reinterpret_cast<vec*>(b + (BF + row0 + i * RPP) * BK + pslotR * EPV) = stg[PL + i];
+    };
+
+    acc_t acc[RI][FI];
+#pragma unroll
+    for (int a = 0; a < RI; ++a)
+#pragma unroll
+        for (int b = 0; b < FI; ++b) acc[a][b] = acc_t{0, 0, 0, 0};
+
+    // fragment rows.  R on the MFMA's i axis; for f64 the accumulator row is q + 4 r, so the tile's rows are
+    // permuted (i -> 4 (i & 3) + (i >> 2)): a lane's registers r = 0..3 are then rows 4 q + r, as for f32.
+    const int ar = sizeof(T) == 8 ? 4 * (i16 & 3) + (i16 >> 2) : i16;
+    const int keyA = sizeof(T) == 8 ? key_of(i16) : (i16 & (SLOTS - 1)), keyB = i16 & (SLOTS - 1);
+    int rowA[RI], rowB[FI];
+#pragma unroll
+    for (int ri = 0; ri < RI; ++ri) rowA[ri] = BF + wr * WR + 16 * ri + ar;
+#pragma unroll
+    for (int fi = 0; fi < FI; ++fi) rowB[fi] = wf * WF + 16 * fi + i16;
+
+    // The update's operands (H and P tiles) are requested before the last slab is multiplied, when they fit the
+    // register budget: their latency then hides behind that slab's MFMAs instead of heading the epilogue.
+    constexpr int TREGS = RI * FI * 4 * (int)sizeof(T) / 4;    // VGPRs of one operand's tiles
+    constexpr bool PREF = MU && TREGS <= 16, PREFP = PREF;
+    vec4 hv[PREF ? RI : 1][PREF ? FI : 1], pv[PREFP ? RI : 1][PREFP ? FI : 1];
+
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    const int nslab = (Kd + BK - 1) / BK;
+    for (int sl = 0; sl < nslab; ++sl) {
+        const int buf = sl & 1;
+        const bool more = sl + 1 < nslab;
+        if (more) fetch((sl + 1) * BK);                   // the next slab's loads fly while this one feeds the MFMAs
+        if (PREF && !more) {
+#pragma unroll
+            for (int fi = 0; fi < (PREF ? FI : 0); ++fi)
+#pragma unroll
+                for (int ri = 0; ri < (PREF ? RI : 0); ++ri) {
+                    const long o = (bf0 + wf * WF + 16 * fi + i16) * ep.ldh + br0 + wr * WR + 16 * ri + 4 * q;
+                    hv[ri][fi] = *reinterpret_cast<const vec4*>(ep.Hin + o);
+                    if (PREFP && !ep.kl) pv[PREFP ? ri : 0][PREFP ? fi : 0] = *reinterpret_cast<const vec4*>(ep.P + o);
+                }
+        }
+        const T* b = sm + buf * (ROWS * BK);
+        const int rest = Kd - sl * BK;
+        const int nkk = rest >= BK ? KK : rest / (4 * EPV);
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+            if (kk < nkk) {
+                vec fa[RI], fb[FI];
+#pragma unroll
+                for (int ri = 0; ri < RI; ++ri)
+                    fa[ri] = *reinterpret_cast<const vec*>(b + rowA[ri] * BK + ((4 * kk + q) ^ keyA) * EPV);
+#pragma unroll
+                for (int fi = 0; fi < FI; ++fi)
+                    fb[fi] = *reinterpret_cast<const vec*>(b + rowB[fi] * BK + ((4 * kk + q) ^ keyB) * EPV);
+#pragma unroll
+                for (int e = 0; e < EPV; ++e)
+#pragma unroll
+                    for (int ri = 0; ri < RI; ++ri)
+#pragma unroll
+                        for (int fi = 0; fi < FI; ++fi) acc[ri][fi] = Mma<T>::mma(fa[ri][e], fb[fi][e], acc[ri][fi]);
+            }
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane (i16, q) holds, per tile, rows 4 q .. 4 q + 3 of R (consecutive columns of C) of frame i16
+#pragma unroll
+    for (int fi = 0; fi < FI; ++fi) {
+        const long t = bf0 + wf * WF + 16 * fi + i16;
+        bool live = true;
+        if (MU) {
+            const int u = ep.frame_utt[t];
+            live = (u >= 0) && (ep.active[u] != 0);
+        }
+#pragma unroll
+        for (int ri = 0; ri < RI; ++ri) {
+            const long n0 = br0 + wr * WR + 16 * ri + 4 * q;
+            vec4 out;
+            if (MU) {
+                const vec4 h = PREF ? hv[PREF ? ri : 0][PREF ? fi : 0] : *reinterpret_cast<const vec4*>(ep.Hin + t * ep.ldh + n0);
+                out = h;
+                if (live) {
+                    if (ep.kl) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) out[r] = h[r] * acc[ri][fi][r];
+                    } else {
+                        const vec4 p = PREFP ? pv[PREFP ? ri : 0][PREFP ? fi : 0] : *reinterpret_cast<const vec4*>(ep.P + t * ep.ldh + n0);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            out[r] = mu_update<T>(h[r], p[r], acc[ri][fi][r], ep.eps_mode, ep.eps, ep.l1);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (n0 + r >= ep.N) out[r] = T(0);       // keep the zero padding exact (0/0 modes)
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[r] = acc[ri][fi][r];
+            }
+            *reinterpret_cast<vec4*>(C + t * ldc + n0) = out;
+        }
+    }
+}
+
+template <typename T, int BF, int BR, int WF, int WR, int BK, bool MU, int MINW>
+static hipError_t launch2(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int I, int J, int Kd,
+                          const MuEpilogue<T>& ep, hipStream_t s, int splits = 1, long slab = 0) {
+    constexpr int NTHR = (BF / WF) * (BR / WR) * 64;
+    const size_t lds = (size_t)2 * (BF + BR) * BK * sizeof(T);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2<T, BF, BR, WF, WR, BK, MU, MINW>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    dim3 grid(J / BR, I / BF, splits), block(NTHR);
+    hipLaunchKernelGGL((k_gemm2<T, BF, BR, WF, WR, BK, MU, MINW>), grid, block, lds, s, L, ldl, R, ldr, C, ldc,
+                       Kd / splits, ep, slab);
+    return hipGetLastError();
+}
+
+template <typename T> static bool aligned16(const T* p, int ld) {
+    return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && ((size_t)ld * sizeof(T)) % 16 == 0;
+}
+
+// can k_gemm2 take this contraction?  (workspace operands always can; Griffin-Lim's strided frames too)
+template <typename T>
+bool gemm2_ok(const T* L, int ldl, const T* R, int ldr, const T* C, int ldc, int I, int J, int Kd) {
+    return I > 0 && J > 0 && Kd > 0 && I % 64 == 0 && J % 64 == 0 && Kd % 16 == 0 && aligned16(L, ldl) &&
+           aligned16(R, ldr) && aligned16(C, ldc);
+}
+
+// LDS row length per dtype: 256-byte rows (deep slab, one 128x128 workgroup per CU) / 128-byte rows
+template <typename T> struct G2K { static constexpr int BIG = 256 / (int)sizeof(T), SMALL = 128 / (int)sizeof(T); };
+
+// Shapes (frames x rows of R, threads, LDS, workgroups per CU):
+//   BIG    128 x 128, 512, 128 KiB, 1   deep slabs: long contractions with plenty of blocks (GRAM)
+//   MID    128 x 128, 512,  64 KiB, 2   (float32 only: float64 accumulators do not fit 128 VGPRs)
+//   SMALL   64 x 128, 256,  48 KiB, 3   finer tile quantisation on 256 CUs, one's epilogue beside the others' MFMAs
+//   SMALL64 64 x  64, 256,  32 KiB, 4   R with a multiple of 64 (not 128) rows: V = H Am^T for M <= 64 mod 128
+template <typename T, bool MU>
+static hipError_t launch_shape(int shape, const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int I, int J, int Kd,
+                               const MuEpilogue<T>& ep, hipStream_t s, int splits, long slab) {
+    switch (shape) {
+        case 0: return launch2<T, 128, 128, 32, 64, G2K<T>::BIG, MU, 2>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s, splits, slab);
+        case 1: return launch2<T, 128, 128, 32, 64, G2K<T>::SMALL, MU, sizeof(T) == 4 ? 4 : 2>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s, splits, slab);
+        case 2: return launch2<T, 64, 128, 32, 64, G2K<T>::SMALL, MU, 3>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s, splits, slab);
+        default: return launch2<T, 64, 64, 32, 32, G2K<T>::SMALL, MU, 3>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s, splits, slab);
+    }
+}
+
+static double round_eff(long wg, long slots) { return (double)wg / (double)(((wg + slots - 1) / slots) * slots); }
+
+// C = L R^T.  With `scratch` (and ldc == J) a short grid is split over k into slabs; see gemm_nt for splits_out.
+template <typename T>
+hipError_t gemm2(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int I, int J, int Kd, hipStream_t s,
+                 T* scratch, size_t scratch_elems, int* splits_out, int n_cus) {
+    if (splits_out) *splits_out = 0;
+    MuEpilogue<T> ep{};
+    if (n_cus <= 0) n_cus = 256;
+    // 64 x 128 blocks (three per CU) when R has a multiple of 128 rows and the grid fills the CUs; 64 x 64 blocks
+    // (four per CU) otherwise: a grid of less than one round runs as long as ONE workgroup does, so the smallest
+    // tile is the fastest
+    const bool wide = J % 128 == 0 && (long)(I / 64) * (J / 128) >= 3L * n_cus;
+    const int shape = wide ? 2 : 3;
+    const long blocks = (long)(I / 64) * (J / (wide ? 128 : 64));
+    const long slots = (long)n_cus * (wide ? 3 : 4);
+    // split-K so that the grid fills the CUs' workgroup slots in whole rounds: the smallest split whose rounds
+    // are >= 85 % full (each workgroup keeps >= 128 of k)
+    int splits = 1;
+    const long slab = (long)I * ldc;
+    if (scratch && ldc == J) {
+        double best = round_eff(blocks, slots);
+        for (int sp = 2; sp <= 32 && best < 0.85; ++sp) {
+            if (Kd % (sp * 16) || Kd / sp < 128 || (size_t)sp * slab > scratch_elems) continue;
+            const double eff = round_eff(blocks * sp, slots);
+            if (eff > best + 0.03) { best = eff; splits = sp; }
+        }
+    }
+    T* out = splits > 1 ? scratch : C;
+    hipError_t e = launch_shape<T, false>(shape, L, ldl, R, ldr, out, ldc, I, J, Kd, ep, s, splits, slab);
+    if (e != hipSuccess || splits == 1) return e;
+    if (splits_out) {          // the caller's next kernel sums the slabs itself (scratch + z * I * ldc, z < splits)
+        *splits_out = splits;
+        return hipSuccess;
+    }
+    return sum_slabs<T>(scratch, slab, splits, C, s);
+}
+
+// the same contraction with the multiplicative update as epilogue: Hout = mu(Hin, P, L R^T)
+template <typename T>
+hipError_t gemm2_mu(const T* L, int ldl, const T* R, int ldr, T* Hout, int I, int J, int Kd,
+                    const MuEpilogue<T>& ep, hipStream_t s) {
+    // The epilogue moves 3 elements per output against 2 Kd flops: for short contractions (Kd of a few hundred) it is as
+    // long as the main loop, so several workgroups share a CU and one's epilogue runs beside the others' MFMAs.
+    // float32: 128 x 128 blocks, two per CU, when there are enough of them for whole rounds; else (and float64,
+    // whose accumulators need the registers) 64 x 128 blocks, three per CU.
+    // A grid of less than one round of 64 x 128 blocks takes the 64 x 64 shape (four per CU): it then runs as long
+    // as one small workgroup does.
+    int dev = 0, n_cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cus <= 0)
+        n_cus = 256;
+    const long b128 = (long)(I / 128) * (J / 128), b64 = (long)(I / 64) * (J / 128);
+    const int shape = (sizeof(T) == 4 && b128 >= 8L * n_cus) ? 1 : (b64 >= 3L * n_cus ? 2 : 3);
+    return launch_shape<T, true>(shape, L, ldl, R, ldr, Hout, ep.ldh, I, J, Kd, ep, s, 1, 0);
+}
+
+#define EVC_INST2(T)                                                                                              \
+    template bool gemm2_ok<T>(const T*, int, const T*, int, const T*, int, int, int, int);                        \
+    template hipError_t gemm2<T>(const T*, int, const T*, int, T*, int, int, int, int, hipStream_t, T*, size_t,  \
+                                 int*, int);                                                                       \
+    template hipError_t gemm2_mu<T>(const T*, int, const T*, int, T*, int, int, int, const MuEpilogue<T>&, hipStream_t);
+EVC_INST2(double)
+EVC_INST2(float)
+
+}  // namespace evc

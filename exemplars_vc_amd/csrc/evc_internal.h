@@ -92,6 +92,19 @@ hipError_t gemm_nt(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int 
 template <typename T>
 hipError_t gemm_nt_mu(const T* L, int ldl, const T* R, int ldr, T* Hout, int I, int J, int Kd,
                       const MuEpilogue<T>& ep, hipStream_t s);
+// ----- evc_gemm2.hip: second-generation contraction kernel (swizzled row-major LDS, 16-byte fragment reads,
+// vector epilogue); gemm_nt / gemm_nt_mu route to it whenever shapes and alignment allow -----
+template <typename T>
+bool gemm2_ok(const T* L, int ldl, const T* R, int ldr, const T* C, int ldc, int I, int J, int Kd);
+template <typename T>
+hipError_t gemm2(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int I, int J, int Kd, hipStream_t s,
+                 T* scratch, size_t scratch_elems, int* splits_out, int n_cus);
+template <typename T>
+hipError_t gemm2_mu(const T* L, int ldl, const T* R, int ldr, T* Hout, int I, int J, int Kd,
+                    const MuEpilogue<T>& ep, hipStream_t s);
+// C = sum_z part[z * slab + .]  (fixed order)
+template <typename T>
+hipError_t sum_slabs(const T* part, long slab, int splits, T* C, hipStream_t s);
 // Bounds-checked general-stride contraction on caller memory (used by evc_synthesize):
 // C[i*csi + j*csj] = sum_k L[i*lsi + k*lsk] * R[j*rsj + k*rsk]
 template <typename T>
