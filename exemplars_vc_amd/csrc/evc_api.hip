@@ -3,6 +3,7 @@
 #include "evc_internal.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 using namespace evc;
@@ -27,13 +28,16 @@ struct Dims {
     int Mk, Mj, Np, Tp;
 };
 
-Dims make_dims(int M, int N, int T_, int n_utt, int Mb = 0) {
+Dims make_dims(int esize, int M, int N, int T_, int n_utt, int Mb = 0) {
     Dims d;
     d.M = M; d.N = N; d.T_ = T_; d.n_utt = n_utt; d.Mb = Mb;
     d.Mk = round_up(M, 16);
     d.Mj = round_up(M, 64);
     d.Np = round_up(N, 128);
-    d.Tp = round_up(T_, 128);
+    // frames are padded to the contraction kernels' frame tile: 64 where k_gemm2 is in charge (float32; float64 with
+    // EVC_GEMM2_F64 set), 128 for the first-generation kernel (float64; everything with EVC_GEMM_V1 set)
+    static const bool v1 = getenv("EVC_GEMM_V1") != nullptr, v2d = getenv("EVC_GEMM2_F64") != nullptr;
+    d.Tp = round_up(T_, (!v1 && (esize == 4 || v2d)) ? 64 : 128);
     return d;
 }
 
@@ -269,7 +273,7 @@ int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int 
     const T* A = static_cast<const T*>(A_);
     const T* X = static_cast<const T*>(X_);
     T* H = static_cast<T*>(H_);
-    const Dims d = make_dims(M, N, T_, n_utt, y ? y->Mb : 0);
+    const Dims d = make_dims((int)sizeof(T), M, N, T_, n_utt, y ? y->Mb : 0);
     int algo = o.algo == EVC_ALGO_AUTO ? EVC_ALGO_FACTORED : o.algo;
     const int n_slots = n_slots_for(o.iters, o.check_every);
     if (n_slots > MAX_SLOTS) return ST_UNSUPPORTED;
@@ -403,7 +407,7 @@ int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int 
 }
 
 template <typename T> size_t workspace_typed(int M, int Mb, int N, int T_, int n_utt, int algo) {
-    const Dims d = make_dims(M, N, T_, n_utt, Mb);
+    const Dims d = make_dims((int)sizeof(T), M, N, T_, n_utt, Mb);
     const int al = algo == EVC_ALGO_AUTO ? EVC_ALGO_FACTORED : algo;
     const int dt = sizeof(T) == 8 ? EVC_F64 : EVC_F32;
     // callers may disable the fused path per call, so the query covers both carvings
@@ -621,7 +625,7 @@ int evc_residual(const void* A, int lda, const void* X, int ldx, const void* H, 
     if (bad_ld(layout, lda, N, M) || bad_ld(layout, ldx, T, M) || bad_ld(layout, ldh, T, N))
         return ST_BADARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const Dims d = make_dims(M, N, T, 1, 0);
+    const Dims d = make_dims(dtype == EVC_F64 ? 8 : 4, M, N, T, 1, 0);
     const bool fm = (layout == EVC_FRAME_MAJOR);
 #define EVC_RESID(TT)                                                                              \
     {                                                                                              \

@@ -179,10 +179,12 @@ hipError_t sum_slabs(const T* part, long slab, int splits, T* C, hipStream_t s) 
     return hipGetLastError();
 }
 
-// EVC_GEMM_V1=1 in the environment keeps every contraction on k_gemm_nt (A/B timing of the two generations)
-static bool use_gemm2() {
-    static const bool v1 = getenv("EVC_GEMM_V1") != nullptr;
-    return !v1;
+// Which generation of the contraction kernel serves a call: k_gemm2 for float32 (77 against 65 Tflop/s on the
+// STFT flow); float64 stays on k_gemm_nt, which k_gemm2 does not beat (its 64-cycle MFMAs hide what k_gemm2
+// removes).  EVC_GEMM_V1 / EVC_GEMM2_F64 in the environment force one or the other (A/B timing).
+template <typename T> static bool use_gemm2() {
+    static const bool v1 = getenv("EVC_GEMM_V1") != nullptr, v2d = getenv("EVC_GEMM2_F64") != nullptr;
+    return !v1 && (sizeof(T) == 4 || v2d);
 }
 
 template <typename T>
@@ -190,7 +192,7 @@ hipError_t gemm_nt(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int 
                    hipStream_t s, T* scratch, size_t scratch_elems, int* splits_out) {
     if (splits_out) *splits_out = 0;
     if (I <= 0 || J <= 0) return hipSuccess;
-    if (use_gemm2() && gemm2_ok<T>(L, ldl, R, ldr, C, ldc, I, J, Kd)) {
+    if (use_gemm2<T>() && gemm2_ok<T>(L, ldl, R, ldr, C, ldc, I, J, Kd)) {
         int dev = 0, cus = 0;
         if (scratch && (hipGetDevice(&dev) != hipSuccess ||
                         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess))
@@ -233,10 +235,10 @@ template <typename T>
 hipError_t gemm_nt_mu(const T* L, int ldl, const T* R, int ldr, T* Hout, int I, int J, int Kd,
                       const MuEpilogue<T>& ep, hipStream_t s) {
     if (I <= 0 || J <= 0) return hipSuccess;
-    if (I % 128 || J % 128 || Kd % KS || Kd <= 0) return hipErrorInvalidValue;
-    if (use_gemm2() && gemm2_ok<T>(L, ldl, R, ldr, Hout, ep.ldh, I, J, Kd) &&
+    if (use_gemm2<T>() && J % 128 == 0 && gemm2_ok<T>(L, ldl, R, ldr, Hout, ep.ldh, I, J, Kd) &&
         gemm2_ok<T>(ep.Hin, ep.ldh, ep.Hin, ep.ldh, ep.kl ? ep.Hin : ep.P, ep.ldh, I, J, Kd))
         return gemm2_mu<T>(L, ldl, R, ldr, Hout, I, J, Kd, ep, s);
+    if (I % 128 || J % 128 || Kd % KS || Kd <= 0) return hipErrorInvalidValue;
     // Tile quantisation for one or two utterances: 128x128 tiles run in rounds of 256 (one per CU), 64x128
     // tiles in rounds of 512 (two per CU, half the work each; a trailing all-padding row tile leaves at
     // once).  C3 (768 x 8192): 384 full tiles = 2 rounds against 768 half tiles = 2 half rounds.

@@ -24,7 +24,7 @@ template <> struct G2T<float> { typedef float vec __attribute__((ext_vector_type
 
 // BF x BR block (frames x rows of R), WF x WR per wavefront, BK elements of k per slab, MINW: waves per SIMD the
 // register allocation is held to (2 workgroups per CU when the LDS image is 64 KiB)
-template <typename T, int BF, int BR, int WF, int WR, int BK, bool MU, int MINW>
+template <typename T, int BF, int BR, int WF, int WR, int BK, bool MU, int MINW, int DEPTH>
 __global__ __launch_bounds__((BF / WF) * (BR / WR) * 64, MINW) void k_gemm2(
     const T* __restrict__ L, int ldl, const T* __restrict__ R, int ldr, T* __restrict__ C, int ldc, int Kd,
     MuEpilogue<T> ep, long slab) {
@@ -42,7 +42,7 @@ __global__ __launch_bounds__((BF / WF) * (BR / WR) * 64, MINW) void k_gemm2(
     static_assert(SLOTS == 8 || SLOTS == 16, "LDS rows of 128 or 256 bytes");
     static_assert(NTHR % SLOTS == 0 && RPP % SLOTS == 0 && BF % RPP == 0 && BR % RPP == 0, "staging shape");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    T* sm = reinterpret_cast<T*>(smem_raw);               // [2][ROWS][BK]
+    T* sm = reinterpret_cast<T*>(smem_raw);               // [DEPTH + 1][ROWS][BK]
 
     // split-K: blockIdx.z owns k in [z Kd, (z+1) Kd) and writes its partial product to slab z
     L += (long)blockIdx.z * Kd;
@@ -82,22 +82,23 @@ __global__ __launch_bounds__((BF / WF) * (BR / WR) * 64, MINW) void k_gemm2(
     const int pslotR = sizeof(T) == 8 ? slot ^ key_of(4 * (r15 & 3) + (r15 >> 2)) : pslot;
     const T* gl = L + (bf0 + row0) * (long)ldl + slot * EPV;
     const T* gr = R + (br0 + row0) * (long)ldr + slot * EPV;
-    vec stg[PL + PR];
-    auto fetch = [&](int k0) {
+    typedef vec StgSet[PL + PR];
+    StgSet stg[DEPTH];
+    auto fetch = [&](StgSet& st, int k0) {
         const bool in = k0 + slot * EPV < Kd;             // (Kd is a multiple of 16 elements: a slot is all in or all out)
 #pragma unroll
         for (int i = 0; i < PL; ++i)
-            stg[i] = in ? *reinterpret_cast<const vec*>(gl + (long)i * RPP * ldl + k0) : vec(0);
+            st[i] = in ? *reinterpret_cast<const vec*>(gl + (long)i * RPP * ldl + k0) : vec(0);
 #pragma unroll
         for (int i = 0; i < PR; ++i)
-            stg[PL + i] = in ? *reinterpret_cast<const vec*>(gr + (long)i * RPP * ldr + k0) : vec(0);
+            st[PL + i] = in ? *reinterpret_cast<const vec*>(gr + (long)i * RPP * ldr + k0) : vec(0);
     };
-    auto stash = [&](int buf) {
+    auto stash = [&](const StgSet& st, int buf) {
         T* b = sm + buf * (ROWS * BK);
 #pragma unroll
-        for (int i = 0; i < PL; ++i) *reinterpret_cast<vec*>(b + (row0 + i * RPP) * BK + pslot * EPV) = stg[i];
+        for (int i = 0; i < PL; ++i) *reinterpret_cast<vec*>(b + (row0 + i * RPP) * BK + pslot * EPV) = st[i];
 #pragma unroll
-        for (int i = 0; i < PR; ++i) *reinterpret_cast<vec*>(b + (BF + row0 + i * RPP) * BK + pslotR * EPV) = stg[PL + i];
+        for (int i = 0; i < PR; ++i) *reinterpret_cast<vec*>(b + (BF + row0 + i * RPP) * BK + pslotR * EPV) = st[PL + i];
     };
 
     acc_t acc[RI][FI];
@@ -122,24 +123,18 @@ __global__ __launch_bounds__((BF / WF) * (BR / WR) * 64, MINW) void k_gemm2(
     constexpr bool PREF = MU && TREGS <= 16, PREFP = PREF;
     vec4 hv[PREF ? RI : 1][PREF ? FI : 1], pv[PREFP ? RI : 1][PREFP ? FI : 1];
 
-    fetch(0);
-    stash(0);
-    __syncthreads();
     const int nslab = (Kd + BK - 1) / BK;
-    for (int sl = 0; sl < nslab; ++sl) {
-        const int buf = sl & 1;
-        const bool more = sl + 1 < nslab;
-        if (more) fetch((sl + 1) * BK);                   // the next slab's loads fly while this one feeds the MFMAs
-        if (PREF && !more) {
+    auto prefetch_update_operands = [&]() {
 #pragma unroll
-            for (int fi = 0; fi < (PREF ? FI : 0); ++fi)
+        for (int fi = 0; fi < (PREF ? FI : 0); ++fi)
 #pragma unroll
-                for (int ri = 0; ri < (PREF ? RI : 0); ++ri) {
-                    const long o = (bf0 + wf * WF + 16 * fi + i16) * ep.ldh + br0 + wr * WR + 16 * ri + 4 * q;
-                    hv[ri][fi] = *reinterpret_cast<const vec4*>(ep.Hin + o);
-                    if (PREFP && !ep.kl) pv[PREFP ? ri : 0][PREFP ? fi : 0] = *reinterpret_cast<const vec4*>(ep.P + o);
-                }
-        }
+            for (int ri = 0; ri < (PREF ? RI : 0); ++ri) {
+                const long o = (bf0 + wf * WF + 16 * fi + i16) * ep.ldh + br0 + wr * WR + 16 * ri + 4 * q;
+                hv[ri][fi] = *reinterpret_cast<const vec4*>(ep.Hin + o);
+                if (PREFP && !ep.kl) pv[PREFP ? ri : 0][PREFP ? fi : 0] = *reinterpret_cast<const vec4*>(ep.P + o);
+            }
+    };
+    auto compute = [&](int buf, int sl) {
         const T* b = sm + buf * (ROWS * BK);
         const int rest = Kd - sl * BK;
         const int nkk = rest >= BK ? KK : rest / (4 * EPV);
@@ -161,8 +156,39 @@ __global__ __launch_bounds__((BF / WF) * (BR / WR) * 64, MINW) void k_gemm2(
                         for (int fi = 0; fi < FI; ++fi) acc[ri][fi] = Mma<T>::mma(fa[ri][e], fb[fi][e], acc[ri][fi]);
             }
         }
-        if (more) stash(buf ^ 1);
+    };
+    if (DEPTH == 1) {
+        // two LDS buffers; the next slab's loads fly while this one feeds the MFMAs
+        fetch(stg[0], 0);
+        stash(stg[0], 0);
         __syncthreads();
+        for (int sl = 0; sl < nslab; ++sl) {
+            const bool more = sl + 1 < nslab;
+            if (more) fetch(stg[0], (sl + 1) * BK);
+            if (PREF && !more) prefetch_update_operands();
+            compute(sl & 1, sl);
+            if (more) stash(stg[0], (sl + 1) & 1);
+            __syncthreads();
+        }
+    } else {
+        // Short slabs on small tiles (32 MFMAs per wavefront and slab against ~2 us of load latency): TWO slabs are
+        // in flight.  Three LDS buffers; slab sl is in buffer sl % 3, slab sl + 1 in register set (sl + 1) & 1, and
+        // slab sl + 2 is requested into the set slab sl came from.
+        fetch(stg[0], 0);
+        if (nslab > 1) fetch(stg[DEPTH - 1], BK);
+        stash(stg[0], 0);
+        __syncthreads();
+        auto step = [&](StgSet& free_set, const StgSet& next_set, int sl) {
+            if (sl + 2 < nslab) fetch(free_set, (sl + 2) * BK);
+            if (PREF && sl + 1 == nslab) prefetch_update_operands();
+            compute(sl % 3, sl);
+            if (sl + 1 < nslab) stash(next_set, (sl + 1) % 3);
+            __syncthreads();
+        };
+        for (int sl = 0; sl < nslab; sl += 2) {
+            step(stg[0], stg[DEPTH - 1], sl);
+            if (sl + 1 < nslab) step(stg[DEPTH - 1], stg[0], sl + 1);
+        }
     }
 
     // epilogue: lane (i16, q) holds, per tile, rows 4 q .. 4 q + 3 of R (consecutive columns of C) of frame i16
@@ -204,18 +230,18 @@ __global__ __launch_bounds__((BF / WF) * (BR / WR) * 64, MINW) void k_gemm2(
     }
 }
 
-template <typename T, int BF, int BR, int WF, int WR, int BK, bool MU, int MINW>
+template <typename T, int BF, int BR, int WF, int WR, int BK, bool MU, int MINW, int DEPTH = 1>
 static hipError_t launch2(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int I, int J, int Kd,
                           const MuEpilogue<T>& ep, hipStream_t s, int splits = 1, long slab = 0) {
     constexpr int NTHR = (BF / WF) * (BR / WR) * 64;
-    const size_t lds = (size_t)2 * (BF + BR) * BK * sizeof(T);
+    const size_t lds = (size_t)(DEPTH + 1) * (BF + BR) * BK * sizeof(T);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2<T, BF, BR, WF, WR, BK, MU, MINW>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm2<T, BF, BR, WF, WR, BK, MU, MINW, DEPTH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
     dim3 grid(J / BR, I / BF, splits), block(NTHR);
-    hipLaunchKernelGGL((k_gemm2<T, BF, BR, WF, WR, BK, MU, MINW>), grid, block, lds, s, L, ldl, R, ldr, C, ldc,
+    hipLaunchKernelGGL((k_gemm2<T, BF, BR, WF, WR, BK, MU, MINW, DEPTH>), grid, block, lds, s, L, ldl, R, ldr, C, ldc,
                        Kd / splits, ep, slab);
     return hipGetLastError();
 }
@@ -238,7 +264,7 @@ template <typename T> struct G2K { static constexpr int BIG = 256 / (int)sizeof(
 //   BIG    128 x 128, 512, 128 KiB, 1   deep slabs: long contractions with plenty of blocks (GRAM)
 //   MID    128 x 128, 512,  64 KiB, 2   (float32 only: float64 accumulators do not fit 128 VGPRs)
 //   SMALL   64 x 128, 256,  48 KiB, 3   finer tile quantisation on 256 CUs, one's epilogue beside the others' MFMAs
-//   SMALL64 64 x  64, 256,  32 KiB, 4   R with a multiple of 64 (not 128) rows: V = H Am^T for M <= 64 mod 128
+//   SMALL64 64 x  64, 256,  48 KiB, 3 (two slabs in flight)  R with a multiple of 64 (not 128) rows: V = H Am^T for M <= 64 mod 128
 template <typename T, bool MU>
 static hipError_t launch_shape(int shape, const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int I, int J, int Kd,
                                const MuEpilogue<T>& ep, hipStream_t s, int splits, long slab) {
@@ -246,7 +272,7 @@ static hipError_t launch_shape(int shape, const T* L, int ldl, const T* R, int l
         case 0: return launch2<T, 128, 128, 32, 64, G2K<T>::BIG, MU, 2>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s, splits, slab);
         case 1: return launch2<T, 128, 128, 32, 64, G2K<T>::SMALL, MU, sizeof(T) == 4 ? 4 : 2>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s, splits, slab);
         case 2: return launch2<T, 64, 128, 32, 64, G2K<T>::SMALL, MU, 3>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s, splits, slab);
-        default: return launch2<T, 64, 64, 32, 32, G2K<T>::SMALL, MU, 3>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s, splits, slab);
+        default: return launch2<T, 64, 64, 32, 32, G2K<T>::SMALL, MU, 3, 2>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s, splits, slab);
     }
 }
 
@@ -303,7 +329,7 @@ hipError_t gemm2_mu(const T* L, int ldl, const T* R, int ldr, T* Hout, int I, in
         hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cus <= 0)
         n_cus = 256;
     const long b128 = (long)(I / 128) * (J / 128), b64 = (long)(I / 64) * (J / 128);
-    const int shape = (sizeof(T) == 4 && b128 >= 8L * n_cus) ? 1 : (b64 >= 3L * n_cus ? 2 : 3);
+    const int shape = (sizeof(T) == 4 && I % 128 == 0 && b128 >= 8L * n_cus) ? 1 : (b64 >= 3L * n_cus ? 2 : 3);
     return launch_shape<T, true>(shape, L, ldl, R, ldr, Hout, ep.ldh, I, J, Kd, ep, s, 1, 0);
 }
 
