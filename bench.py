@@ -1,20 +1,26 @@
 #!/usr/bin/env python3
 """bench.py - spectral frames/sec converted on the exemplar-NMF activation path.
 
-A "step" is one pass of the hot path over one batch of synthetic utterances already
-resident in HBM: activation solve (K multiplicative updates against the fixed dictionary A,
-scikit-learn semantics as called by 04_align_n_nmf.py: constant init, zero->EPSILON guard,
-fixed K, no early stop) followed by the synthesis Y = B H.  Default workload is BASELINE.json
-configs[1] ("C2"): M=25 bins, N=4096 exemplars, K=100, float64, 256 utterances x 688 frames
-(the reference's corpus is 162 utterances; 256 is the next count whose
-256 x 43 sixteen-frame workgroups fill the 256 CUs in whole rounds).
+A "step" is one pass of the hot path over one batch of synthetic utterances already resident in HBM:
+activation solve (K multiplicative updates against the fixed dictionary A, scikit-learn semantics as called
+by 04_align_n_nmf.py: constant init, zero->EPSILON guard, fixed K, no early stop) followed by the synthesis
+Y = B H.  Default workload is BASELINE.json configs[1] ("C2"): M=25 bins, N=4096 exemplars, K=100, float64,
+256 utterances x 688 frames (the reference's corpus is 162 utterances; 256 is the next count
+whose frame tiles fill the 256 CUs in whole rounds).
 
-  python bench.py [--gpus N --steps K --warmup W]
+  python bench.py [--gpus N --steps K --warmup W] [--config C1|C2|C3|C5|C5_513|STFT]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N>1: one process per GPU, utterances sharded (independent shards, no data-path
-collective; torch.distributed is used for the barrier and the max-over-ranks only).
-Prints ONE JSON line on rank 0.
+N>1: one process per GPU, utterances sharded (independent shards, no data-path collective;
+torch.distributed is used for the barrier and the max-over-ranks only).  Prints ONE JSON line on rank 0.
+
+Besides the contract's fields the line carries
+  roofline       algorithmic flops of the executed algebra / HIP-event time of the iteration loop (recorded by the
+                 library on the launch stream), against the dense matrix peak of the arithmetic type
+  cpu_baseline   the oracle's restatement of the reference's scikit-learn call on this box's cores (median of 3),
+                 plus the installed scikit-learn, the pymf-literal algebra and a one-thread run (rank 0, N=1 only)
+  pcie           the same step with X uploaded from and Y (and H) downloaded to page-locked host memory inside the
+                 wall (SURVEY.md 8d's definition of the metric for numpy callers); never the headline `value`
 """
 import argparse
 import json
@@ -27,11 +33,27 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# MI355X peaks (/opt/skills/guides/MI355X_MICROARCH.md: FP64 vector/matrix 78.6 TFLOP/s is the
-# public datasheet number quoted in SURVEY.md section 8d; HBM3E 8 TB/s spec)
+# MI355X peaks (/opt/skills/guides/MI355X_MICROARCH.md; FP64 vector/matrix 78.6 TFLOP/s is the public datasheet
+# number quoted in SURVEY.md section 8d; HBM3E 8 TB/s spec)
 PEAK_F64_TFLOPS = 78.6
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+
+# BASELINE.json configurations: per-GPU batch = utterances x frames.  C4 is C2 sharded (--gpus N).
+PRESETS = {
+    "C1": dict(bins=25, exemplars=512, iters=50, utterances=256, frames=688, dtype="f64", l1=0.0,
+               label="C1 (BASELINE configs[0]): the reference's CPU-runnable case"),
+    "C2": dict(bins=25, exemplars=4096, iters=100, utterances=256, frames=688, dtype="f64", l1=0.0,
+               label="C2 (BASELINE configs[1])"),
+    "C3": dict(bins=513, exemplars=8192, iters=200, utterances=1, frames=688, dtype="f64", l1=0.0,
+               label="C3 (BASELINE configs[2]): WORLD-width spectra, one utterance per call"),
+    "C5": dict(bins=25, exemplars=16384, iters=100, utterances=16, frames=688, dtype="f64", l1=0.25,
+               label="C5 (BASELINE configs[4]): L1-penalised, N=16384"),
+    "C5_513": dict(bins=513, exemplars=16384, iters=100, utterances=1, frames=688, dtype="f64", l1=5.13,
+                   label="C5 at WORLD width (M=513)"),
+    "STFT": dict(bins=201, exemplars=4096, iters=150, utterances=16, frames=688, dtype="f32", l1=0.0,
+                 label="the script's own default flow: |Re STFT| of a complex64 transform, float32, M=201"),
+}
 
 
 def algorithmic_flops_per_frame(M, N, K, Mb, algo):
@@ -52,32 +74,89 @@ def loop_flops_per_frame(M, N, K, algo):
     return K * (4 * M * N + 3 * N)
 
 
-def cpu_baseline(M, N, K, seed, budget_frames):
-    """The reference CPU path on this box's host cores, on a bounded sample of the same
-    workload: one utterance (688 frames) through the oracle's restatement of what
-    04_align_n_nmf.py executes (scikit-learn MU, Gram and numerator hoisted), float64, all
-    BLAS threads.  kind = "port" (the oracle; bit-exact against scikit-learn 1.7.2)."""
-    from oracle import evc_oracle as o
-    T = budget_frames
-    p = o.synth_problem(M, N, T, seed=seed)
-    X_rows = np.ascontiguousarray(p["X"].T)
-    W_rows = np.ascontiguousarray(p["A"].T)
-    B_rows = np.ascontiguousarray(p["B"].T)
-    o.sklearn_mu_fixed_dictionary(X_rows[:32], W_rows, max_iter=2, tol=0.0)     # BLAS thread pool warm-up
+# ------------------------------------------------------------------------------------------------
+# multi-process bookkeeping (exercised on CPU over gloo by tests/test_bench_dist.py)
+# ------------------------------------------------------------------------------------------------
+def dist_env(same_device=False):
+    """(world, rank, local_rank) from the launcher's environment (torch.distributed.run)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = 0 if same_device else int(os.environ.get("LOCAL_RANK", "0"))
+    return world, rank, local_rank
+
+
+def run_timed(step, steps, warmup, barrier):
+    """W untimed warm-up steps, then EXACTLY `steps` steps bracketed by `barrier()` on both sides; seconds."""
+    for _ in range(warmup):
+        step(False)
+    barrier()
     t0 = time.perf_counter()
-    act, n_iter, _ = o.sklearn_mu_fixed_dictionary(X_rows, W_rows, max_iter=K, tol=0.0)
-    Y = o.s4_convert(act.T, B_rows)
-    dt = time.perf_counter() - t0
-    out = {"value": T / dt, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port",
-           "sample": f"1 utterance of {T} frames, M={M} N={N} K={K}, float64, oracle restatement of the "
-                     f"scikit-learn MU call of 04_align_n_nmf.py:212 + np.matmul(H.T,B); {dt:.2f} s wall",
-           "seconds": dt}
+    for _ in range(steps):
+        step(True)
+    barrier()
+    return time.perf_counter() - t0
+
+
+def max_over_ranks(elapsed, dist=None, device=None):
+    """the slowest rank's time (what the whole job took)"""
+    if dist is None:
+        return float(elapsed)
+    import torch
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def job_throughput(world, units_per_rank, steps, elapsed):
+    """whole-job aggregate: every rank processed `units_per_rank` units per step (weak scaling)"""
+    return world * units_per_rank * steps / elapsed
+
+
+# ------------------------------------------------------------------------------------------------
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_sample_frames(N, frames):
+    """a bounded sample: the scikit-learn algebra costs 2 N^2 flop per frame-iteration (Gram), ~7 s per run at
+    N=4096 on 64 cores for a 688-frame utterance; larger dictionaries get proportionally fewer frames"""
+    return max(16, min(frames, int(frames * (4096.0 / N) ** 2)))
+
+
+def cpu_baseline(M, N, K, l1, dtype, seed, T):
+    """The reference CPU path on this box's host cores, on a bounded sample of the same workload: the oracle's
+    restatement of what 04_align_n_nmf.py executes (scikit-learn MU, Gram and numerator hoisted), all BLAS threads,
+    median of 3 runs after a warm-up.  kind = "port" (the oracle; bit-exact against scikit-learn 1.7.2)."""
+    from oracle import evc_oracle as o
+    npdt = np.float64 if dtype == "f64" else np.float32
+    p = o.synth_problem(M, N, T, seed=seed)
+    X_rows = np.ascontiguousarray(p["X"].T).astype(npdt)
+    W_rows = np.ascontiguousarray(p["A"].T).astype(npdt)
+    B_rows = np.ascontiguousarray(p["B"].T).astype(npdt)
+    o.sklearn_mu_fixed_dictionary(X_rows[:32], W_rows, max_iter=2, tol=0.0, l1_reg=l1)     # BLAS pool warm-up
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        act, n_iter, _ = o.sklearn_mu_fixed_dictionary(X_rows, W_rows, max_iter=K, tol=0.0, l1_reg=l1)
+        Y = o.s4_convert(act.T, B_rows)
+        times.append(time.perf_counter() - t0)
+    dt = float(np.median(times))
+    out = {"value": T / dt, "unit": "frames/s", "cores": os.cpu_count(), "kind": "port", "cpu_model": cpu_model(),
+           "sample": f"{T} frames of one utterance, M={M} N={N} K={K} l1={l1}, {dtype}, oracle restatement of the "
+                     f"scikit-learn MU call of 04_align_n_nmf.py:212 + np.matmul(H.T,B); median of 3 runs "
+                     f"({', '.join(f'{t:.2f}' for t in times)} s)",
+           "seconds": dt, "runs_s": times}
     try:
         import threadpoolctl
         info = threadpoolctl.threadpool_info()
         out["blas"] = [{"api": i.get("internal_api"), "threads": i.get("num_threads"),
                         "lib": os.path.basename(i.get("filepath", ""))} for i in info]
-        # the threads the timed numpy GEMMs actually ran on: numpy's own BLAS pool
         mine = [i for i in info if i.get("user_api") == "blas" and "numpy" in i.get("filepath", "")]
         if not mine:
             mine = [i for i in info if i.get("user_api") == "blas"]
@@ -85,37 +164,55 @@ def cpu_baseline(M, N, K, seed, budget_frames):
             out["cores"] = int(mine[0].get("num_threads", 1))
     except Exception:
         pass
-    # pymf-literal (Gram and numerator recomputed per iteration) on a quarter of the frames
-    Tq = max(16, T // 4)
-    H0 = np.random.default_rng(1).random((N, Tq)) + 1e-4
+    # pymf-literal (Gram and numerator recomputed per iteration) on a sixteenth of the frames
+    Tq = max(16, T // 16)
+    H0 = (np.random.default_rng(1).random((N, Tq)) + 1e-4)
     t0 = time.perf_counter()
     o.pymf_factorize(p["X"][:, :Tq], p["A"], H0, niter=K, compute_err=False)
-    dtl = time.perf_counter() - t0
-    out["pymf_literal_frames_per_s"] = Tq / dtl
+    out["pymf_literal_frames_per_s"] = Tq / (time.perf_counter() - t0)
+    out["pymf_literal_sample_frames"] = Tq
     # the installed scikit-learn itself (what 04_align_n_nmf.py:212 calls), same sample, all threads
     try:
         import warnings
         from sklearn.decomposition import non_negative_factorization
+        kw = dict(alpha_W=l1 / M, l1_ratio=1.0) if l1 > 0 else {}
         t0 = time.perf_counter()
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             non_negative_factorization(X=X_rows, H=W_rows, init="custom", update_H=False, n_components=N,
-                                       beta_loss="frobenius", solver="mu", tol=0, max_iter=K)
+                                       beta_loss="frobenius", solver="mu", tol=0, max_iter=K, **kw)
         out["sklearn_installed_frames_per_s"] = T / (time.perf_counter() - t0)
     except Exception as e:  # noqa: BLE001
         out["sklearn_installed_frames_per_s"] = None
         out["sklearn_note"] = repr(e)[:120]
-    # one BLAS thread, an eighth of the utterance
+    # one BLAS thread, an eighth of the sample
     try:
         import threadpoolctl
         T8 = max(16, T // 8)
         with threadpoolctl.threadpool_limits(limits=1):
             t0 = time.perf_counter()
-            o.sklearn_mu_fixed_dictionary(X_rows[:T8], W_rows, max_iter=K, tol=0.0)
+            o.sklearn_mu_fixed_dictionary(X_rows[:T8], W_rows, max_iter=K, tol=0.0, l1_reg=l1)
             out["single_thread_frames_per_s"] = T8 / (time.perf_counter() - t0)
+            out["single_thread_sample_frames"] = T8
     except Exception:
         pass
     return out, (p, act, Y)
+
+
+def pmc_traffic(kernel_tag, M, N, K, T, dtype):
+    """HBM bytes per launch of the dominant kernel from a committed rocprofv3 PMC summary of this very workload
+    (rocprofv3 cannot run inside the timed process); (None, reason) when no matching file is on record."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json")), reverse=True):
+        try:
+            pm = json.load(open(path))
+            wl = pm["workload"]
+            if (wl["M"], wl["N"], wl["K"], wl["frames"], wl["dtype"]) == (M, N, K, T, dtype) and \
+                    kernel_tag in pm.get("kernel", ""):
+                return pm["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    return None, "no PMC summary under profiles/ matches this workload and kernel"
 
 
 def main():
@@ -123,32 +220,38 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--bins", type=int, default=25)
-    ap.add_argument("--exemplars", type=int, default=4096)
-    ap.add_argument("--iters", type=int, default=100)
-    ap.add_argument("--utterances", type=int, default=256)
-    ap.add_argument("--frames", type=int, default=688, help="frames per utterance")
+    ap.add_argument("--config", default="C2", choices=sorted(PRESETS), help="BASELINE configuration preset")
+    ap.add_argument("--bins", type=int)
+    ap.add_argument("--exemplars", type=int)
+    ap.add_argument("--iters", type=int)
+    ap.add_argument("--utterances", type=int)
+    ap.add_argument("--frames", type=int, help="frames per utterance")
+    ap.add_argument("--l1", type=float)
     ap.add_argument("--algo", default="factored", choices=["factored", "gram", "literal"])
-    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--dtype", choices=["f64", "f32"])
     ap.add_argument("--loss", default="frobenius", choices=["frobenius", "kl"],
                     help="kl: the KL update of _factorize's signature default (not the headline metric)")
     ap.add_argument("--no-fused", action="store_true")
+    ap.add_argument("--no-all-resident", action="store_true", help="A/B: keep k_fused_all out")
     ap.add_argument("--fused-c", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--cpu-frames", type=int, default=688)
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-transfer-inclusive leg")
+    ap.add_argument("--cpu-frames", type=int, default=0, help="frames of the CPU sample (0: bounded automatically)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend for N>1 (nccl = RCCL)")
     ap.add_argument("--same-device", action="store_true",
                     help="testing only: every rank uses cuda:0 (rehearse the N>1 path on a 1-GPU box)")
     args = ap.parse_args()
+    cfg = dict(PRESETS[args.config])
+    for k in ("bins", "exemplars", "iters", "utterances", "frames", "l1", "dtype"):
+        if getattr(args, k) is not None:
+            cfg[k] = getattr(args, k)
+    custom = any(getattr(args, k) is not None for k in ("bins", "exemplars", "iters", "utterances", "frames", "l1", "dtype"))
 
     import torch
     import exemplars_vc_amd as evc
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.same_device:
-        local_rank = 0
+    world, rank, local_rank = dist_env(args.same_device)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -159,10 +262,11 @@ def main():
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
 
-    M, N, K = args.bins, args.exemplars, args.iters
-    U, Tu = args.utterances, args.frames
+    M, N, K, l1 = cfg["bins"], cfg["exemplars"], cfg["iters"], cfg["l1"]
+    U, Tu = cfg["utterances"], cfg["frames"]
     T = U * Tu
-    tdt = torch.float64 if args.dtype == "f64" else torch.float32
+    dtype = cfg["dtype"]
+    tdt = torch.float64 if dtype == "f64" else torch.float32
 
     # synthetic shard of this rank (SURVEY.md 8d recipe, generated on the device in float64):
     # unit-L2 dictionary columns, ~8 active exemplars per frame, X = A H* + 1e-6
@@ -173,10 +277,13 @@ def main():
     B = torch.rand(N, M, generator=g, device=dev, dtype=torch.float64) + 1e-3
     B /= B.norm(dim=1, keepdim=True)
     g.manual_seed(1000 + rank)
-    Hs = torch.rand(T, N, generator=g, device=dev, dtype=torch.float64)
-    Hs *= (torch.rand(T, N, generator=g, device=dev, dtype=torch.float64) < (8.0 / N))
-    X = Hs @ A + 1e-6
-    del Hs
+    X = torch.empty(T, M, device=dev, dtype=torch.float64)
+    for a0 in range(0, T, 16384):       # in slices: the T x N helper matrices of a large batch would not fit
+        a1 = min(T, a0 + 16384)
+        Hs = torch.rand(a1 - a0, N, generator=g, device=dev, dtype=torch.float64)
+        Hs *= (torch.rand(a1 - a0, N, generator=g, device=dev, dtype=torch.float64) < (8.0 / N))
+        X[a0:a1] = Hs @ A + 1e-6
+        del Hs
     A, B, X = A.to(tdt), B.to(tdt), X.to(tdt).contiguous()
     offs = np.arange(U + 1, dtype=np.int32) * Tu
     H = torch.empty(T, N, dtype=tdt, device=dev)
@@ -185,119 +292,134 @@ def main():
     ev0.record(); ev1.record()          # force creation of the underlying hipEvent_t
     torch.cuda.synchronize()
     loop_ms = []
+    solve_kw = dict(layout="frame_major", iters=K, eps_mode="zero_replace", init="sklearn", algo=args.algo, l1=l1,
+                    fused=not args.no_fused, fused_c=args.fused_c, loss=args.loss,
+                    all_resident=not args.no_all_resident)
 
     def step(timed):
         # factorize() + convert(): H (T x N) and Y = H B (T x Mb) both delivered in HBM
-        _, Y = evc.convert(A, X, B, layout="frame_major", iters=K, eps_mode="zero_replace",
-                           init="sklearn", algo=args.algo, utt_offsets=offs, out=H, out_y=Yout,
-                           fused=not args.no_fused, fused_c=args.fused_c, loop_events=(ev0, ev1),
-                           loss=args.loss)
+        _, Y = evc.convert(A, X, B, utt_offsets=offs, out=H, out_y=Yout, loop_events=(ev0, ev1), **solve_kw)
         if timed:
             ev1.synchronize()
             loop_ms.append(ev0.elapsed_time(ev1))
         return Y
 
     def barrier():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        Y = step(True)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = run_timed(step, args.steps, args.warmup, barrier)
+    elapsed = max_over_ranks(elapsed, dist, dev if (dist is not None and args.dist_backend == "nccl") else None)
 
     if rank == 0:
-        value = world * T * args.steps / elapsed
+        value = job_throughput(world, T, args.steps, elapsed)
         loop_s = float(np.mean(loop_ms)) / 1e3
         fl_loop = loop_flops_per_frame(M, N, K, args.algo) * T
         achieved = fl_loop / loop_s / 1e12
         fused = args.algo == "factored" and M <= 32 and not args.no_fused
         # float32 callers with M <= 32 are widened onto the float64 fused kernels: the arithmetic type is f64
-        arith = "f64" if (args.dtype == "f64" or fused) else "f32"
+        arith = "f64" if (dtype == "f64" or fused) else "f32"
         peak = PEAK_F64_TFLOPS if arith == "f64" else PEAK_F32_TFLOPS
-        # HBM bytes per launch from the committed PMC passes of this very workload (rocprofv3 cannot
-        # run inside the timed process); null when the profile on file is for another workload
-        traffic = None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_bench_c2.json")))
-            wl = pm["workload"]
-            if fused and (wl["M"], wl["N"], wl["K"], wl["frames"], wl["dtype"]) == (M, N, K, T, args.dtype):  # noqa: E501
-                traffic = pm["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
+        if fused:
+            all_res = (not args.no_all_resident) and N % 512 == 0 and (N // 512) in (1, 2, 4, 8) and args.loss == "frobenius"
+            kernel = ("k_fused_all (persistent: H and P register-resident, two members per CU alternating sweep / "
+                      "exchange)" if all_res else "k_fused_res (persistent, half of H register-resident, P recomputed)")
+            ktag = "k_fused_all" if all_res else "k_fused_res"
+        else:
+            kernel = ("k_gemm2" if arith == "f32" else "k_gemm_nt") + " x2 per iteration (V = H Am^T, then the update as epilogue of V At^T)"
+            ktag = "k_gemm2" if arith == "f32" else "k_gemm_nt"
+        traffic, traffic_src = pmc_traffic(ktag, M, N, K, T, dtype)
         res = {
-            "metric": "spectral frames/sec converted (100 NMF iters, N=4096 dict)",
+            "metric": "spectral frames/sec converted (100 NMF iters, N=4096 dict)" if (N, K) == (4096, 100)
+                      else f"spectral frames/sec converted ({K} NMF iters, N={N} dict)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": arith, "data": "synthetic",
-            "config": {"workload": f"C2 (BASELINE configs[1]): SF1->TF1-shaped dictionary, M={M} bins, "
-                                   f"N={N} exemplars, K={K} MU iterations, {U} utterances x {Tu} frames "
-                                   f"= {T} frames per GPU per step, solve + synthesis B*H",
-                       "algo": args.algo, "kernel": "k_fused_res (persistent, register-resident, 1 launch per step)" if fused
-                       else "k_gemm_nt(+mu epilogue), launches per iteration",
-                       "frames_per_gpu": T, "parallelism": f"utterance shards x{world}", "io_dtype": args.dtype},
+            "config": {"workload": ("custom: " if custom else cfg["label"] + ": ") +
+                                   f"SF1->TF1-shaped dictionary, M={M} bins, N={N} exemplars, K={K} MU iterations"
+                                   f"{f', L1 {l1}' if l1 else ''}, {U} utterance(s) x {Tu} frames = {T} frames per GPU "
+                                   f"per step, solve + synthesis B*H, {dtype} in and out",
+                       "preset": args.config if not custom else None,
+                       "algo": args.algo, "kernel": kernel,
+                       "frames_per_gpu": T, "parallelism": f"utterance shards x{world}", "io_dtype": dtype},
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                "frac": achieved / peak, "traffic": traffic,
-                "kernel": "iteration loop (k_fused_res)" if fused else "iteration loop (k_gemm_nt family)",
+                "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": f"iteration loop ({ktag})",
                 "launch_ms": 1e3 * loop_s,
                 "algorithmic_flops_per_launch": fl_loop,
-                "note": "achieved = algorithmic flops of the executed algebra (K*(4MN+3N) per frame "
-                        "for FACTORED) / HIP-event time of the loop launches on the launch stream",
+                "note": "achieved = algorithmic flops of the executed algebra (K*(4MN+3N) per frame for FACTORED) / "
+                        "HIP-event time of the loop launches, recorded on the launch stream",
             },
             "algorithmic_gflop_per_frame": algorithmic_flops_per_frame(M, N, K, M, args.algo) / 1e9,
         }
         if args.loss != "frobenius":
             res["config"]["loss"] = args.loss
             res["roofline"]["note"] = "KL update: flop count of the Frobenius update is NOT applicable; see value only"
+        if not args.no_pcie and world == 1:
+            # wall including the upload of X and the download of Y (and of H for callers that want
+            # the activations), page-locked host memory.  Reported beside the headline, never as `value`.
+            Xh = torch.empty(X.shape, dtype=tdt, pin_memory=True); Xh.copy_(X)
+            Yh = torch.empty(Yout.shape, dtype=tdt, pin_memory=True)
+            pc = {}
+            for name, with_h in (("xy", False), ("xyh", True)):
+                if with_h and H.numel() * H.element_size() > 8 * 2 ** 30:
+                    pc[name] = None
+                    continue
+                Hh = torch.empty(H.shape, dtype=tdt, pin_memory=True) if with_h else None
+                reps = 2
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(reps):
+                    X.copy_(Xh, non_blocking=True)
+                    step(False)
+                    Yh.copy_(Yout, non_blocking=True)
+                    if with_h:
+                        Hh.copy_(H, non_blocking=True)
+                    torch.cuda.synchronize()
+                pc[name] = T * reps / (time.perf_counter() - t0)
+                del Hh
+            res["pcie"] = {"frames_per_s_upload_X_download_Y": pc["xy"],
+                           "frames_per_s_upload_X_download_Y_and_H": pc["xyh"],
+                           "note": "page-locked host buffers, transfers on the launch stream inside the wall; H is "
+                                   f"{N * (8 if dtype == 'f64' else 4)} bytes per frame"}
         if not args.no_cpu and args.loss == "frobenius" and world == 1:   # CPU leg: rank 0 at N=1 only
-            cpu, (p, act_cpu, Y_cpu) = cpu_baseline(M, N, K, 20190131, args.cpu_frames)
+            Tc = args.cpu_frames or cpu_sample_frames(N, Tu)
+            cpu, (p, act_cpu, Y_cpu) = cpu_baseline(M, N, K, l1, dtype, 20190131, Tc)
             res["cpu_baseline"] = cpu
             # conservative: against the faster of the oracle port and the installed scikit-learn
             res["speedup_vs_cpu"] = value / max(cpu["value"], cpu.get("sklearn_installed_frames_per_s") or 0.0)
             # parity of the GPU path on the very sample the CPU leg timed
-            Xs = np.ascontiguousarray(p["X"].T)
-            Hg, Yg = evc.convert(np.ascontiguousarray(p["A"].T), Xs, np.ascontiguousarray(p["B"].T),
-                                 layout="frame_major", iters=K, eps_mode="zero_replace", init="sklearn",
-                                 algo=args.algo, dtype=args.dtype, fused=not args.no_fused)
+            npdt = np.float64 if dtype == "f64" else np.float32
+            Xs = np.ascontiguousarray(p["X"].T).astype(npdt)
+            As, Bs = np.ascontiguousarray(p["A"].T).astype(npdt), np.ascontiguousarray(p["B"].T).astype(npdt)
+            kw = dict(solve_kw); kw["dtype"] = dtype
+            Hg, Yg = evc.convert(As, Xs, Bs, **kw)
             nz = act_cpu != 0
-            # a lone utterance takes the cooperative launch; the timed batch runs one workgroup per frame
-            # tile: check that variant of the kernel on the same sample too
-            Hb = evc.solve_activations(np.ascontiguousarray(p["A"].T), Xs, layout="frame_major", iters=K,
-                                       eps_mode="zero_replace", init="sklearn", algo=args.algo, dtype=args.dtype,
-                                       fused=not args.no_fused, cooperative=False)
+            # the timed batch may run another launch mode than a lone utterance: check both on the same sample
+            kw2 = dict(kw); kw2["cooperative"] = False; kw2["all_resident"] = False
+            Hb = evc.solve_activations(As, Xs, **kw2)
             res["parity"] = {
                 "H_max_rel_err": float(np.max(np.abs(Hg[nz] - act_cpu[nz]) / act_cpu[nz])),
-                "H_max_rel_err_batch_kernel": float(np.max(np.abs(Hb[nz] - act_cpu[nz]) / act_cpu[nz])),
+                "H_max_rel_err_no_exchange_kernels": float(np.max(np.abs(Hb[nz] - act_cpu[nz]) / act_cpu[nz])),
                 "Y_max_rel_err": float(np.max(np.abs(Yg - Y_cpu) / np.abs(Y_cpu))),
-                "rtol_required": 1e-4,
+                "rtol_required": 1e-4, "sample_frames": Tc,
             }
             # latency of ONE utterance (device-resident inputs, solve + synthesis): the reference's call pattern
-            n1 = args.cpu_frames
+            n1 = min(Tu, T)
             X1, H1, Y1 = X[:n1], H[:n1], Yout[:n1]
-            l0, l1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            l0, l1e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             for rep in range(13):
                 if rep == 3:
                     l0.record()
-                evc.convert(A, X1, B, layout="frame_major", iters=K, eps_mode="zero_replace", init="sklearn",
-                            algo=args.algo, out=H1, out_y=Y1, fused=not args.no_fused, loss=args.loss)
-            l1.record()
+                evc.convert(A, X1, B, out=H1, out_y=Y1, **solve_kw)
+            l1e.record()
             torch.cuda.synchronize()
-            ms1 = l0.elapsed_time(l1) / 10.0
-            res["one_utterance"] = {"frames": n1, "ms": ms1, "frames_per_s": n1 / ms1 * 1e3,
-                                    "note": "cooperative launch: several workgroups per 16-frame tile"}
+            ms1 = l0.elapsed_time(l1e) / 10.0
+            res["one_utterance"] = {"frames": n1, "ms": ms1, "frames_per_s": n1 / ms1 * 1e3}
         print(json.dumps(res))
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

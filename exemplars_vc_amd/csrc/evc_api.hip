@@ -213,8 +213,9 @@ int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_sol
         fb.coop_c = fused_res_coop_factor(w.fl.NT, w.fl.TT, cus);
     const bool exchanges = fb.coop_c > 1 || fb.all_c > 1;
     int* coop_abort = fb.coop_cnt + COOP_MAX_TILES;
-    // reserved bit 3 (tests): start with the abort flag raised, so that the call takes the retry path below
-    if (exchanges) HIP_TRY(hipMemsetAsync(coop_abort, (o.reserved & 8) ? 1 : 0, sizeof(int), s));
+    // tests only (environment, not part of the ABI): EVC_TEST_COOP_ABORT starts the call with the abort flag raised,
+    // so that it takes the retry path below
+    if (exchanges) HIP_TRY(hipMemsetAsync(coop_abort, getenv("EVC_TEST_COOP_ABORT") ? 1 : 0, sizeof(int), s));
     int first = 1;
     if (o.check_every > 0 && o.stop_rule == EVC_STOP_SKLEARN) {   // error_at_init
         HIP_TRY(fused_iterate(w.fl, fb, w.u, d.N, d.T_, 0, 1, 1, w.err2, o.eps_mode, o.eps, o.l1,

@@ -121,6 +121,18 @@ __global__ __launch_bounds__(DTW_THREADS) void k_dtw_accumulate(DtwArgs g) {
     }
 }
 
+// doff[p] = sum over pairs before p of Ta * Tb (one wavefront; the corpus has 162 pairs)
+__global__ void k_dtw_offsets(const int* __restrict__ aoff, const int* __restrict__ boff, long* __restrict__ doff,
+                              int n_pairs) {
+    if (threadIdx.x != 0) return;
+    long acc = 0;
+    doff[0] = 0;
+    for (int q = 0; q < n_pairs; ++q) {
+        acc += (long)(aoff[q + 1] - aoff[q]) * (long)(boff[q + 1] - boff[q]);
+        doff[q + 1] = acc;
+    }
+}
+
 size_t dtw_workspace_bytes(const int* aoff, const int* boff, int n_pairs) {
     size_t cells = 0;
     for (int p = 0; p < n_pairs; ++p)
@@ -138,24 +150,19 @@ hipError_t dtw_run(const double* A, long lda, const int* aoff, const double* B, 
     int* d_boff = reinterpret_cast<int*>(p); p += (((size_t)(n_pairs + 1) * sizeof(int)) + 255) & ~size_t(255);
     long* d_doff = reinterpret_cast<long*>(p); p += (((size_t)(n_pairs + 1) * sizeof(long)) + 255) & ~size_t(255);
     double* Dm = reinterpret_cast<double*>(p);
-    // element offsets of the per-pair matrices (small, host side)
-    long doff_small[257];
-    long* doff = n_pairs + 1 <= 257 ? doff_small : new long[n_pairs + 1];
+    // launch geometry from the caller's offsets; the element offsets of the per-pair matrices are a prefix sum
+    // formed on the device (no host temporary, so no allocation and no synchronisation here)
     long maxcells = 0;
     int maxTa = 0;
-    doff[0] = 0;
     for (int q = 0; q < n_pairs; ++q) {
         const long Ta = aoff[q + 1] - aoff[q], Tb = boff[q + 1] - boff[q];
-        doff[q + 1] = doff[q] + Ta * Tb;
         if (Ta * Tb > maxcells) maxcells = Ta * Tb;
         if (Ta > maxTa) maxTa = (int)Ta;
     }
     hipError_t e = hipMemcpyAsync(d_aoff, aoff, sizeof(int) * (n_pairs + 1), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) e = hipMemcpyAsync(d_boff, boff, sizeof(int) * (n_pairs + 1), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_doff, doff, sizeof(long) * (n_pairs + 1), hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);       // `doff` is a host temporary
-    if (doff != doff_small) delete[] doff;
     if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_dtw_offsets, dim3(1), dim3(64), 0, s, d_aoff, d_boff, d_doff, n_pairs);
     DtwArgs g{A, lda, B, ldb, d_aoff, d_boff, d_doff, Dm, path_a, path_b, path_len, total, D};
     if (maxcells > 0) {
         hipLaunchKernelGGL(k_dtw_cost, dim3((unsigned)((maxcells + 255) / 256), n_pairs), dim3(256), 0, s, g);

@@ -12,6 +12,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import os
 import threading
 from typing import Optional, Sequence
 
@@ -230,13 +231,14 @@ def _solve(A, X, H0, B, *, layout="bin_major", iters=100, eps_mode="add", eps=No
     opts.eps = _EPS_DEFAULT[eps_mode] if eps is None else float(eps)
     opts.l1, opts.tol, opts.init_value = float(l1), float(tol), float(init_value)
     opts.loss = _LOSSES[loss]
-    # knobs: bit 0 disables the fused persistent kernels; bit 1 asks for correctly rounded quotients in them;
-    # bit 2 disables the cooperative launch used for one or two utterances; bits 8..15 = 1 or 2 force the
-    # general streamed kernel with that many frame tiles per workgroup (0 = automatic); bit 4 disables the
-    # all-resident kernel (k_fused_all: NT / 32 workgroups per frame tile, nothing streams)
-    opts.reserved = ((0 if fused else 1) | (2 if exact_div else 0) | (0 if cooperative else 4)
-                     | (8 if _fake_coop_timeout else 0) | (0 if all_resident else 16)
-                     | ((int(fused_c) & 0xff) << 8))
+    # EVC_FLAG_* of include/evc.h: NO_FUSED, EXACT_DIV, NO_EXCHANGE (cooperative=False: no kernel in which
+    # workgroups exchange data inside a launch - the call is then fully asynchronous), NO_ALL_RESIDENT; bits
+    # 8..15 = 1 or 2 force the general streamed kernel with that many frame tiles per workgroup (tuning)
+    opts.reserved = ((0 if fused else _lib.FLAG_NO_FUSED) | (_lib.FLAG_EXACT_DIV if exact_div else 0)
+                     | (0 if cooperative else _lib.FLAG_NO_EXCHANGE)
+                     | (0 if all_resident else _lib.FLAG_NO_ALL_RESIDENT) | ((int(fused_c) & 0xff) << 8))
+    if _fake_coop_timeout:      # tests: the library reads this from the environment, it is not part of the ABI
+        os.environ["EVC_TEST_COOP_ABORT"] = "1"
     if loop_events is not None:     # (torch.cuda.Event, torch.cuda.Event), already created
         opts.ev_loop_start = int(loop_events[0].cuda_event)
         opts.ev_loop_stop = int(loop_events[1].cuda_event)
@@ -260,6 +262,8 @@ def _solve(A, X, H0, B, *, layout="bin_major", iters=100, eps_mode="add", eps=No
                 A_d.data_ptr(), _ld(A_d), X_d.data_ptr(), _ld(X_d), B_d.data_ptr(), _ld(B_d),
                 h_ptr, h_ld, Y_d.data_ptr(), _ld(Y_d), M, Mb, N, T, off_ptr, n_utt, C.byref(opts),
                 ws.data_ptr(), ws.numel(), ni_p, er_p, C.c_void_p(stream))
+    if _fake_coop_timeout:
+        os.environ.pop("EVC_TEST_COOP_ABORT", None)
     _lib.check(st, "evc_nmf_solve" if B is None else "evc_nmf_convert")
     to_np = x_np and out is None
     H_out = None if H_d is None else (_to_host(H_d) if to_np else H_d)

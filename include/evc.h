@@ -25,10 +25,15 @@
  *   All pointers are DEVICE pointers unless marked "host".  Nothing here allocates,
  *   frees or throws; every function returns a status (0 ok; -1 invalid argument, -2 workspace
  *   too small, -3 unsupported combination, -4 cooperative launch timed out twice (not reachable:
- *   the redo is not cooperative); >0 a hipError_t value).  Work is enqueued on `stream`; the host
- *   synchronises only to hand back n_iter/err when those host pointers are non-NULL, and once per
- *   call that took the cooperative launch (a few frame tiles: one or two utterances), to learn
- *   whether it has to be redone.
+ *   the redo is not cooperative); >0 a hipError_t value).  Work is enqueued on `stream`.
+ *   Host synchronisation - exactly these cases, nothing else waits:
+ *     (1) n_iter_out / err_out / rmse_out non-NULL: the call returns after copying them back;
+ *     (2) evc_nmf_solve / evc_nmf_convert on the float64 fused path (M <= 32) when several workgroups
+ *         share a frame tile and exchange partial sums inside a launch (k_fused_all for N > 512,
+ *         the cooperative k_fused_res launch for one or two utterances): one round trip at the end
+ *         of the call reads the flag that tells whether a workgroup gave up waiting for its peers (then
+ *         the solve is redone without any exchange).  EVC_FLAG_NO_EXCHANGE keeps such a call fully
+ *         asynchronous (at about half the speed for a lone utterance, ~10 % less for large batches).
  *   No global mutable state: calls on distinct streams/devices are independent and the
  *   caller's current device (hipSetDevice) is honoured.
  */
@@ -93,6 +98,14 @@ enum { EVC_STOP_NONE = 0, EVC_STOP_SKLEARN = 1, EVC_STOP_PYMF = 2 };
  *              to the stopping rule is sqrt(2 KL(X || A H)) (_nmf.py:136-160)                      */
 enum { EVC_LOSS_FROBENIUS = 0, EVC_LOSS_KL = 1 };
 
+/* evc_solve_opts.reserved
+ *   NO_FUSED         the generic two-contraction path instead of the fused persistent kernels (M <= 32)
+ *   EXACT_DIV        correctly rounded quotients in the fused kernels (always on with EVC_STOP_PYMF)
+ *   NO_EXCHANGE      no kernel in which workgroups exchange data inside a launch: the call is then fully
+ *                    asynchronous (see "Host synchronisation" above); a latency / determinism knob
+ *   NO_ALL_RESIDENT  keep k_fused_all out (k_fused_res, with its cooperative launch for few frame tiles) */
+enum { EVC_FLAG_NO_FUSED = 1, EVC_FLAG_EXACT_DIV = 2, EVC_FLAG_NO_EXCHANGE = 4, EVC_FLAG_NO_ALL_RESIDENT = 16 };
+
 typedef struct evc_solve_opts {
     int struct_bytes;  /* sizeof(evc_solve_opts), for forward compatibility */
     int dtype;         /* EVC_F64 | EVC_F32 */
@@ -103,9 +116,8 @@ typedef struct evc_solve_opts {
     int init_mode;     /* EVC_INIT_* */
     int check_every;   /* 0: never evaluate the residual; k>0: every k iterations */
     int stop_rule;     /* EVC_STOP_* */
-    int reserved;      /* 0; knobs: bit 0 = no fused kernels, bit 1 = correctly rounded quotients in the
-                          fused kernels (always on with EVC_STOP_PYMF), bit 2 = no cooperative launch, bit 3 = (tests) pretend the cooperative launch timed out,
-                          bits 8..15 = 1|2 general kernel */
+    int reserved;      /* flags, 0 = defaults: an OR of EVC_FLAG_* (below); bits 8..15: tuning only - 1 | 2 force the
+                          general streamed kernel with that many frame tiles per workgroup */
     int loss;          /* EVC_LOSS_* */
     int reserved2;     /* 0 */
     double eps;        /* guard value for eps_mode */

@@ -75,3 +75,11 @@ def test_bad_arguments_are_rejected_before_any_device_work():
     assert conv(None, 25) == -1            # H0 must be given when init is GIVEN
     assert L.evc_synthesize(one, 1, one, 64, one, 25, 25, 64, 10, 0, 0, None) == -1   # ldb < Mb
     assert L.evc_synthesize(one, 25, one, 64, one, 25, 25, 64, 0, 0, 0, None) == 0
+
+
+def test_flag_constants_match_the_header():
+    _lib, _ = lib()
+    hdr = open(os.path.join(ROOT, "include", "evc.h")).read()
+    for name in ("NO_FUSED", "EXACT_DIV", "NO_EXCHANGE", "NO_ALL_RESIDENT"):
+        m = re.search(rf"EVC_FLAG_{name}\s*=\s*(\d+)", hdr)
+        assert m and int(m.group(1)) == getattr(_lib, f"FLAG_{name}"), name

@@ -232,3 +232,41 @@ def test_single_frame_at_real_width():
     assert_close64(H, act.T, "T=1, M=513")
     Y = evc.synthesize(np.ascontiguousarray(p["B"].T), H.T.copy(), layout="frame_major")
     assert_close64(Y, act @ p["B"].T, "T=1 synthesis")
+
+
+def test_two_host_threads_on_two_streams():
+    """include/evc.h: calls on distinct streams are independent.  The Python surface keeps one scratch buffer per
+    (device, stream): two host threads, each on its own stream, solve different problems at the same time (generic
+    path and fused path - both use the scratch heavily) and must each get the result of a solo run."""
+    import threading
+    import torch
+    import exemplars_vc_amd as evc
+    o = oracle()
+    probs = [o.synth_problem(201, 512, 300, seed=1), o.synth_problem(25, 1024, 700, seed=2)]
+    kw = dict(iters=40, eps_mode="zero_replace", init="sklearn", cooperative=False)
+    solo = [evc.solve_activations(p["A"], p["X"], **kw) for p in probs]
+    dev = torch.device("cuda")
+    res, errs = [[None] * 6, [None] * 6], []
+
+    def work(i):
+        try:
+            st = torch.cuda.Stream(device=dev)
+            A = torch.from_numpy(probs[i]["A"]).to(dev)
+            X = torch.from_numpy(probs[i]["X"]).to(dev)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(st):
+                for r in range(6):
+                    res[i][r] = evc.solve_activations(A, X, **kw)
+                st.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        for r in range(6):
+            assert np.array_equal(res[i][r].cpu().numpy(), solo[i]), (i, r)

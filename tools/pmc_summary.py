@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc csv output per kernel (evc kernels only): mean per dispatch.
-usage: pmc_summary.py <pmc dir> [--json out.json M N K frames]   (the json is what bench.py reads for
-roofline.traffic: HBM bytes per launch of the dominant kernel, gfx950 corrections applied)"""
+usage: pmc_summary.py <pmc dir> [--json out.json M N K frames dtype kernel_tag]
+(the json is what bench.py reads for roofline.traffic: HBM bytes per launch of the dominant kernel, with the
+gfx950 corrections of /opt/skills/guides/MI355X_MICROARCH.md applied: FETCH_SIZE x 2 for wide coalesced reads,
+WRITE_SIZE exact; both counters are reported in KiB)"""
 import csv
 import glob
+import json
 import os
 import sys
 from collections import defaultdict
@@ -24,25 +27,39 @@ for k in sorted(acc):
         print(f"   {c:28s} n={len(v):3d} mean={sum(v)/len(v):.6g}")
 
 if "--json" in sys.argv:
-    import json
     i = sys.argv.index("--json")
-    dest, (M, N, K, frames) = sys.argv[i + 1], map(int, sys.argv[i + 2:i + 6])
-    name = max((k for k in acc if "k_fused_res" in k), key=lambda k: sum(acc[k].get("SQ_INSTS_MFMA", [0])))
+    dest = sys.argv[i + 1]
+    M, N, K, frames = map(int, sys.argv[i + 2:i + 6])
+    dtype, tag = sys.argv[i + 6], sys.argv[i + 7]
+    # the dominant kernel: the one matching `tag` that issued the most MFMAs in total
+    name = max((k for k in acc if tag in k), key=lambda k: sum(acc[k].get("SQ_INSTS_MFMA", [0])))
     c = {n: sum(v) / len(v) for n, v in acc[name].items()}
-    streamed = 0.5                      # k_fused_res keeps every other exemplar tile in registers
+    w = 8 if dtype == "f64" else 4
+    if "k_fused_all" in name:       # H read once and written once per launch; nothing else streams
+        algorithmic = frames * N * w * 2
+        note = "k_fused_all: activations read once and written once per launch, dictionary fragments from L2"
+    elif "k_fused_res" in name:     # every other exemplar tile streams (read + write) per iteration
+        algorithmic = int(frames * N * w * (2 * 0.5 * K + 2 * 0.5))
+        note = "k_fused_res: half of the activation tiles stream once per iteration"
+    else:                           # the update contraction: H and P read, H written, per launch (one iteration)
+        algorithmic = frames * N * w * 3
+        note = "update contraction: H and P read, H' written once per launch (= per iteration)"
     doc = {
         "kernel": name.replace("evc::", ""),
-        "workload": {"M": M, "N": N, "K": K, "frames": frames, "dtype": "f64"},
-        "source": "rocprofv3 --pmc, separate passes (tools/pmc_fused.sh): FETCH_SIZE; WRITE_SIZE TCC_HIT_sum TCC_MISS_sum; SQ_*",
-        "FETCH_SIZE_kb": c["FETCH_SIZE"], "WRITE_SIZE_kb": c["WRITE_SIZE"],
+        "workload": {"M": M, "N": N, "K": K, "frames": frames, "dtype": dtype},
+        "source": "rocprofv3 --pmc, separate passes (tools/prof_case.sh / tools/pmc_fused.sh): FETCH_SIZE; "
+                  "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum; SQ_*",
+        "FETCH_SIZE_kb": c.get("FETCH_SIZE"), "WRITE_SIZE_kb": c.get("WRITE_SIZE"),
         "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide (16 B/lane) coalesced reads -> x2 "
                       "(MI355X_MICROARCH.md, HBM); WRITE_SIZE exact for 16 B/lane stores",
-        "hbm_bytes_per_launch": 1024.0 * (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]),
-        "algorithmic_hbm_bytes_per_launch": int(frames * N * 8 * (2 * streamed * K + 2 * (1 - streamed))),
-        "mfma_busy_cycles": c["SQ_VALU_MFMA_BUSY_CYCLES"],
-        "gui_active_cycles_sum_xcd": c["GRBM_GUI_ACTIVE"],
+        "hbm_bytes_per_launch": 1024.0 * (2 * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)),
+        "algorithmic_hbm_bytes_per_launch": algorithmic, "algorithmic_note": note,
+        "mfma_busy_cycles": c.get("SQ_VALU_MFMA_BUSY_CYCLES"),
+        "gui_active_cycles_sum_xcd": c.get("GRBM_GUI_ACTIVE"),
         # busy cycles are summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs (128 SIMDs each)
-        "mfma_pipe_occupancy": c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] * 128.0),
-        "valu_insts_per_mfma": c["SQ_INSTS_VALU"] / c["SQ_INSTS_MFMA"],
+        "mfma_pipe_occupancy": (c["SQ_VALU_MFMA_BUSY_CYCLES"] / (c["GRBM_GUI_ACTIVE"] * 128.0)
+                                if c.get("SQ_VALU_MFMA_BUSY_CYCLES") and c.get("GRBM_GUI_ACTIVE") else None),
+        "valu_insts_per_mfma": (c["SQ_INSTS_VALU"] / c["SQ_INSTS_MFMA"]
+                                if c.get("SQ_INSTS_MFMA") else None),
     }
     json.dump(doc, open(dest, "w"), indent=1)
