@@ -92,7 +92,8 @@ Workspace<T> carve(void* base, const Dims& d, int algo, int n_slots, bool fused)
         w.fb.Xp = c.take<double>(w.fl.xp);
         w.fb.Hp = c.take<double>(w.fl.hp);
         w.fb.Vp = c.take<double>(w.fl.vp);
-        w.fb.coop_buf = c.take<double>((size_t)2 * (ALL_MAX_WGS > COOP_MAX_TILES ? ALL_MAX_WGS : COOP_MAX_TILES) * 512);
+        static_assert(ALL_MAX_WGS >= COOP_MAX_TILES, "coop_buf is sized by k_fused_all's layout");
+        w.fb.coop_buf = c.take<double>((size_t)(ALL_SLICE_OFFSET + ALL_SLICE_ELEMS));
         w.fb.coop_cnt = c.take<int>(COOP_MAX_TILES + 1);
         w.fb.coop_c = 1;
     }
@@ -207,7 +208,7 @@ int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_sol
     // reserved bit 4 switches that kernel off, bit 2 every form of inter-workgroup exchange
     if (c_override == 0 && !(o.reserved & 16)) {
         const int c = fused_all_members(w.fl.NT, d.N, o.eps_mode, exact_div, o.loss);
-        if (c == 1 || (c > 1 && !(o.reserved & 4))) fb.all_c = c;
+        if (c == 1 || (c > 1 && c <= cus && !(o.reserved & 4))) fb.all_c = c;
     }
     if (!fb.all_c && !(o.reserved & 4) && c_override == 0 && fused_res_supported(d.N, o.eps_mode, exact_div))
         fb.coop_c = fused_res_coop_factor(w.fl.NT, w.fl.TT, cus);

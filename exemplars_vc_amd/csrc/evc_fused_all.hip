@@ -69,15 +69,20 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
     __shared__ double s_red[2][AW * E];          // partial V' of every wavefront, per half
     __shared__ double s_v[2][E];                 // V, B-operand order
     __shared__ double s_x[2][E];                 // X, B-operand order
+    __shared__ double s_stage[2][C ? 1 : 512];   // reduce-scatter staging (more than 8 members only)
+    __shared__ unsigned s_hb[2];                 // arrivals of a half's wavefronts at its LDS barrier
     __shared__ int s_fail;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = w8 >> 2, w = w8 & 3, th = tid & (AW * 64 - 1);
-    const int member = blockIdx.x % C;
-    const int g = 2 * (blockIdx.x / C) + half;           // the group this half is a member of
+    const int CR = C ? C : a.coop_c;                     // members per group (C == 0: 16, 32 or 64, at run time)
+    const int member = blockIdx.x % CR;
+    const int g = 2 * (blockIdx.x / CR) + half;          // the group this half is a member of
     double* const red = s_red[half];
     double* const vL = s_v[half];
     double* const xL = s_x[half];
+    double* const stage = s_stage[half];
+    unsigned hb = 0;                             // arrivals expected at this half's next LDS barrier
     const double* __restrict__ A1p = a.A1p;
     const double* __restrict__ A2p = a.A2p;
     f64x2* __restrict__ Hp = a.Hp;
@@ -121,6 +126,7 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
     const unsigned lo = fast_lo(mode, eps);
     unsigned seq = 0;                            // exchanges done by this half's group so far
     if (tid == 0) s_fail = 0;
+    if (tid < 2) s_hb[tid] = 0;
 
     for (long tt0 = g - half; tt0 < a.TT; tt0 += a.groups) {     // half 0's tile decides (it has the lower index)
         const long tt = tt0 + half;
@@ -211,7 +217,78 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
                     s0 += red[ww * E + e0];
                     s1 += red[ww * E + (has1 ? e1 : e0)];
                 }
-                if (C > 1) {
+                if (C == 0) {
+                    // ---- more than 8 members (N > 4096): reduce-scatter + all-gather.  Fetching every member's
+                    // partial (C - 1 x 3.5 KB per member and exchange: 108 KB at C = 32) would make the exchange far
+                    // longer than the sweep it hides behind.  Instead member m sums slice m (NE / C elements) of
+                    // all C partials and publishes it; everybody then fetches the C summed slices: 7 KB per member
+                    // and exchange whatever C is, for a second memory round trip - which the alternation hides.
+                    const int ES = NE / CR;                          // elements per slice (CR divides 64)
+                    long long* xb1 = reinterpret_cast<long long*>(a.coop_buf) +
+                                     ((size_t)(seq & 1) * a.groups + g) * (size_t)CR * 512;
+                    long long* xb2 = reinterpret_cast<long long*>(a.coop_buf) + ALL_SLICE_OFFSET +
+                                     ((size_t)(seq & 1) * a.groups + g) * 512;
+                    const long long tag = (seq >> 1) & 1;
+                    // partials: [slice j][member m][ES], so that what member j reduces is one contiguous run
+                    {
+                        const int j0 = e0 / ES, j1 = (has1 ? e1 : e0) / ES;
+                        __hip_atomic_store(xb1 + ((size_t)j0 * CR + member) * ES + (e0 - j0 * ES),
+                                           (__double_as_longlong(s0) & ~1LL) | tag, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                        if (has1)
+                            __hip_atomic_store(xb1 + ((size_t)j1 * CR + member) * ES + (e1 - j1 * ES),
+                                               (__double_as_longlong(s1) & ~1LL) | tag, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    bool ok = true;
+                    // poll two words (one memory round trip for both) until each carries the epoch of this exchange
+                    auto fetch2 = [&](const long long* p0, const long long* p1, long long& b0, long long& b1) {
+                        unsigned polls = 0;
+                        for (;;) {
+                            b0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            b1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (__all(!ok || (((b0 ^ tag) | (b1 ^ tag)) & 1) == 0)) break;
+                            if (++polls > ALL_POLL_LIMIT ||
+                                ((polls & 63) == 0 &&
+                                 __hip_atomic_load(a.coop_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+                                ok = false;
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    };
+                    // reduce: my slice of all CR partials (NE words, contiguous: fully coalesced) goes through LDS;
+                    // the half's 4 wavefronts meet at an LDS counter (a workgroup barrier would stop the other
+                    // half's sweep); then 4 lanes per element sum CR / 4 members each in fixed order and combine
+                    // (a fixed tree: every member obtains the bitwise identical V')
+                    {
+                        long long b0, b1;
+                        const long long* mine_ = xb1 + (size_t)member * NE;
+                        fetch2(mine_ + e0, mine_ + (has1 ? e1 : e0), b0, b1);
+                        stage[e0] = __longlong_as_double(b0 & ~1LL);
+                        if (has1) stage[e1] = __longlong_as_double(b1 & ~1LL);
+                        hb += AW;
+                        if (lane == 0)
+                            __hip_atomic_fetch_add(&s_hb[half], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        while ((int)(__hip_atomic_load(&s_hb[half], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - hb) < 0)
+                            __builtin_amdgcn_s_sleep(1);
+                        if (th < 4 * ES) {
+                            const int el = th >> 2, q = th & 3, per = CR >> 2;
+                            double v = 0.0;
+                            for (int i = 0; i < per; ++i) v += stage[(q * per + i) * ES + el];
+                            v += __shfl_xor(v, 1, 64);
+                            v += __shfl_xor(v, 2, 64);
+                            if (q == 0)
+                                __hip_atomic_store(xb2 + member * ES + el, (__double_as_longlong(v) & ~1LL) | tag,
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                    // gather: the C summed slices
+                    long long g0, g1;
+                    fetch2(xb2 + e0, xb2 + (has1 ? e1 : e0), g0, g1);
+                    s0 = __longlong_as_double(g0 & ~1LL);
+                    s1 = __longlong_as_double(g1 & ~1LL);
+                    ++seq;
+                    if (!ok) s_fail = 1;
+                } else if (C > 1) {
                     long long* xb = reinterpret_cast<long long*>(a.coop_buf) +
                                     ((size_t)(seq & 1) * a.groups + g) * (size_t)(C * 512);
                     const long long tag = (seq >> 1) & 1;        // a buffer is reused every second exchange
@@ -238,7 +315,7 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
                     }
                     // every thread fetches its elements of all members; each word carries its own epoch bit, so
                     // a word that lags behind the watched one is simply fetched again
-                    long long b0[C] = {}, b1[C] = {};
+                    long long b0[C ? C : 1] = {}, b1[C ? C : 1] = {};
                     polls = 0;
                     while (ok) {
 #pragma unroll
@@ -278,7 +355,7 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
             EVC_STAMP(1);
             __syncthreads();
             EVC_STAMP(2);
-            if (C > 1 && s_fail) {               // a peer never showed up: void the launch, let everybody leave
+            if (C != 1 && s_fail) {              // a peer never showed up: void the launch, let everybody leave
                 if (tid == 0) __hip_atomic_store(a.coop_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 return;
             }
@@ -320,17 +397,24 @@ static hipError_t launch_all(FusedArgs a, int n_cus, hipStream_t s) {
     if (occ < 1) return hipErrorInvalidValue;
     long resident = n_cus;                       // one workgroup (two members) per CU
     if (2 * resident > ALL_MAX_WGS) resident = ALL_MAX_WGS / 2;
-    int pairs = (int)(resident / C);             // pairs of groups
+    const int cr = C ? C : a.coop_c;
+    if (C == 0 && (cr < 16 || cr > 64 || (cr & (cr - 1)))) return hipErrorInvalidValue;
+    int pairs = (int)(resident / cr);            // pairs of groups
     const int want = (a.TT + 1) / 2;
     if (pairs > want) pairs = want;
     if (pairs < 1) return hipErrorInvalidValue;
     a.groups = 2 * pairs;
-    if (C > 1) {
+    if (C != 1) {
         // stale words must not carry the epoch bit of the first two exchanges (0): fill with ones
-        e = hipMemsetAsync(a.coop_buf, 0xFF, sizeof(double) * 2 * (size_t)a.groups * C * 512, s);
+        e = hipMemsetAsync(a.coop_buf, 0xFF, sizeof(double) * 2 * (size_t)a.groups * cr * 512, s);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_fused_all<MSTEPS, C>), dim3((unsigned)(pairs * C)), dim3(ATHREADS), 0, s, a);
+    if (C == 0) {
+        if (2L * a.groups * 512 > ALL_SLICE_ELEMS) return hipErrorInvalidValue;
+        e = hipMemsetAsync(a.coop_buf + ALL_SLICE_OFFSET, 0xFF, sizeof(double) * 2 * (size_t)a.groups * 512, s);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_fused_all<MSTEPS, C>), dim3((unsigned)(pairs * cr)), dim3(ATHREADS), 0, s, a);
     return hipGetLastError();
 }
 
@@ -341,6 +425,9 @@ static hipError_t pick_c(const FusedArgs& a, int n_cus, hipStream_t s) {
         case 2: return launch_all<MSTEPS, 2>(a, n_cus, s);
         case 4: return launch_all<MSTEPS, 4>(a, n_cus, s);
         case 8: return launch_all<MSTEPS, 8>(a, n_cus, s);
+        case 16:
+        case 32:
+        case 64: return launch_all<MSTEPS, 0>(a, n_cus, s);
         default: return hipErrorInvalidValue;
     }
 }
@@ -350,7 +437,7 @@ int fused_all_members(int NT, int N, int eps_mode, int exact_div, int loss) {
     if (eps_mode == EVC_EPS_NONE || exact_div || loss != EVC_LOSS_FROBENIUS) return 0;
     if (NT % ATILES) return 0;
     const int c = NT / ATILES;
-    return (c == 1 || c == 2 || c == 4 || c == 8) ? c : 0;
+    return (c >= 1 && c <= 64 && (c & (c - 1)) == 0) ? c : 0;
 }
 
 hipError_t fused_all_launch(int msteps, const FusedArgs& a, int n_cus, hipStream_t s) {
