@@ -37,8 +37,13 @@
 // the exchange before).  Every wait is bounded; a member that gives up raises coop_abort, everybody leaves,
 // and the host redoes the solve without inter-workgroup communication (evc_api.hip).
 //
+// More than 8 members (N = 8192 .. 32768, template C == 0, member count at run time): fetching every peer's
+// partial would cost (C - 1) x 3.5 KB per member and exchange, so the exchange becomes a reduce-scatter +
+// all-gather (see the C == 0 branch): two memory round trips, 7 KB fetched per member whatever C is.
+// Measured at N = 16384 (C5): 5.8 us per step against 5.2 us at N = 4096, where the sweep is the longer half.
+//
 // Requirements (the host checks them, fused_all_members): guarded eps mode, fast quotients, Frobenius
-// loss, NT a multiple of 32.  Frame tiles whose frames are not all live are left to the general kernel
+// loss, NT a multiple of 32, NT / 32 a power of two <= 64.  Frame tiles whose frames are not all live are left to the general kernel
 // (skip_all_live), like in k_fused_res.
 #include "evc_fused_common.h"
 

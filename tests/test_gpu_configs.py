@@ -110,6 +110,23 @@ def test_c5_full_size(M):
         assert_close64(Hn, H, "C5 without exchange", rtol=1e-10)
 
 
+@pytest.mark.parametrize("M,N", [(25, 8192), (25, 32768), (13, 16384), (32, 8192), (4, 16384)])
+def test_reduce_scatter_exchange_member_counts(M, N):
+    """k_fused_all with 16, 32 and 64 members per frame tile (reduce-scatter exchange), bins that fill 1, 4, 7
+    and 8 k-steps: against the oracle, against the kernels without exchange, and twice for bitwise equality
+    (every member must obtain the same V' whatever the arrival order)."""
+    import exemplars_vc_amd as evc
+    o = oracle()
+    K, T = 30, 200                        # 13 frame tiles: more groups than tiles at 16 members
+    p = o.synth_problem(M, N, T, seed=N + M)
+    H = evc.solve_activations(p["A"], p["X"], iters=K, eps_mode="zero_replace", init="sklearn")
+    _slice_check(p, H, N, K, 0.0, f"M={M} N={N}", frames=32)
+    Hn = evc.solve_activations(p["A"], p["X"], iters=K, eps_mode="zero_replace", init="sklearn", cooperative=False)
+    assert_close64(H, Hn, "against the kernels without exchange", rtol=1e-10)
+    H2 = evc.solve_activations(p["A"], p["X"], iters=K, eps_mode="zero_replace", init="sklearn")
+    assert np.array_equal(H, H2), "two runs of the exchange must agree bit for bit"
+
+
 def _c4_problem(n_utt=162, N=4096, M=25, seed=4):
     o = oracle()
     p = o.synth_problem(M, N, 0, seed=seed)
