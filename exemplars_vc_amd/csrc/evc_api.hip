@@ -355,7 +355,7 @@ int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int 
     bool v_valid = false;
 
     auto residual_check = [&](int c) -> int {
-        if (!v_valid) HIP_TRY(gemm_nt<T>(Hc, d.Np, w.Am, d.Np, w.Vt, d.Mj, d.Tp, d.Mj, d.Np, s, w.Vsplit, w.vsplit_elems));
+        if (!v_valid) HIP_TRY(gemm_nt<T>(Hc, d.Np, w.Am, d.Np, w.Vt, d.Mj, d.Tp, d.Mj, d.Np, s, w.Vsplit, w.vsplit_elems, nullptr, d.Mk));
         v_valid = true;
         if (kl) HIP_TRY(frame_err_kl<T>(w.Xt, d.Mk, w.Vt, d.Mj, M, T_, o.eps, w.err2, s));
         else HIP_TRY(frame_err2<T>(w.Xt, d.Mk, w.Vt, d.Mj, M, T_, w.err2, s));
@@ -383,7 +383,7 @@ int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int 
             HIP_TRY(gemm_nt_mu<T>(Hc, d.Np, w.G, d.Np, Hn, d.Tp, d.Np, d.Np, ep, s));
             T* tmp = Hc; Hc = Hn; Hn = tmp;
         } else {
-            if (!v_valid) HIP_TRY(gemm_nt<T>(Hc, d.Np, w.Am, d.Np, w.Vt, d.Mj, d.Tp, d.Mj, d.Np, s, w.Vsplit, w.vsplit_elems));
+            if (!v_valid) HIP_TRY(gemm_nt<T>(Hc, d.Np, w.Am, d.Np, w.Vt, d.Mj, d.Tp, d.Mj, d.Np, s, w.Vsplit, w.vsplit_elems, nullptr, d.Mk));
             ep.Hin = Hc;
             if (kl) {                     // H' = H (.) (X (/) max(V, eps)) (A / colsum)   sklearn _nmf.py:556-606
                 HIP_TRY(kl_ratio<T>(w.Xt, d.Mk, w.Vt, d.Mj, M, d.Tp, o.eps, w.Rt, d.Mk, s));
@@ -636,7 +636,7 @@ int evc_residual(const void* A, int lda, const void* X, int ldx, const void* H, 
         HIP_TRY(copy2d<TT>((const TT*)A, lda, M, N, fm ? 1 : 0, w.Am, d.Np, d.Mj, d.Np, 0, s));     \
         HIP_TRY(copy2d<TT>((const TT*)X, ldx, T, M, fm ? 0 : 1, w.Xt, d.Mk, d.Tp, d.Mk, 0, s));     \
         HIP_TRY(copy2d<TT>((const TT*)H, ldh, T, N, fm ? 0 : 1, w.H0, d.Np, d.Tp, d.Np, 0, s));     \
-        HIP_TRY(gemm_nt<TT>(w.H0, d.Np, w.Am, d.Np, w.Vt, d.Mj, d.Tp, d.Mj, d.Np, s));              \
+        HIP_TRY(gemm_nt<TT>(w.H0, d.Np, w.Am, d.Np, w.Vt, d.Mj, d.Tp, d.Mj, d.Np, s, nullptr, 0, nullptr, d.Mk));              \
         HIP_TRY(frame_err2<TT>(w.Xt, d.Mk, w.Vt, d.Mj, M, T, err2_out, s));                         \
     }
     if (dtype == EVC_F64) EVC_RESID(double) else EVC_RESID(float)

@@ -27,7 +27,7 @@ template <typename T, int E> struct VecOf { typedef T type __attribute__((ext_ve
 template <typename T, int BM, int BN, int WM, int WN, bool MU>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_gemm_nt(
     const T* __restrict__ L, int ldl, const T* __restrict__ R, int ldr, T* __restrict__ C, int ldc,
-    int Kd, MuEpilogue<T> ep, long slab) {
+    int Kd, MuEpilogue<T> ep, long slab, int jv) {
     // split-K: blockIdx.z owns k in [z Kd, (z+1) Kd) and writes its partial product to slab z
     L += (long)blockIdx.z * Kd;
     R += (long)blockIdx.z * Kd;
@@ -46,10 +46,12 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_gemm_nt(
     __shared__ T sR[2][KS][BN + 1];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, w = tid >> 6;
+    const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w / NWN, wn = w % NWN;
     const int i16 = lane & 15, q = lane >> 4;
     const long bi = (long)blockIdx.y * BM, bj = (long)blockIdx.x * BN;
+    (void)jv;   // (k_gemm2 skips the zero rows of R from jv on; here the guards cost more than the products)
+    constexpr int nni = NI;
 
     if (MU) {
         // a block whose frames all belong to stopped utterances only carries H over
@@ -103,11 +105,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_gemm_nt(
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) a[mi] = sL[buf][kk][wm * WM + 16 * mi + i16];
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) b[ni] = sR[buf][kk][wn * WN + 16 * ni + i16];
+            for (int ni = 0; ni < NI; ++ni)
+                if (ni < nni) b[ni] = sR[buf][kk][wn * WN + 16 * ni + i16];
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+            for (int ni = 0; ni < NI; ++ni)
+                if (ni < nni) {
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = Mma<T>::mma(a[mi], b[ni], acc[mi][ni]);
+                    for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = Mma<T>::mma(a[mi], b[ni], acc[mi][ni]);
+                }
         }
         if (more) {
 #pragma unroll
@@ -154,10 +159,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_gemm_nt(
 
 template <typename T, int BM, int BN, int WM, int WN, bool MU>
 static hipError_t launch_nt(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int I, int J,
-                            int Kd, const MuEpilogue<T>& ep, hipStream_t s, int splits = 1, long slab = 0) {
+                            int Kd, const MuEpilogue<T>& ep, hipStream_t s, int splits = 1, long slab = 0, int jv = 0) {
     dim3 grid(J / BN, I / BM, splits), block((BM / WM) * (BN / WN) * 64);
     hipLaunchKernelGGL((k_gemm_nt<T, BM, BN, WM, WN, MU>), grid, block, 0, s, L, ldl, R, ldr, C, ldc,
-                       Kd / splits, ep, slab);
+                       Kd / splits, ep, slab, jv > 0 ? jv : J);
     return hipGetLastError();
 }
 
@@ -189,7 +194,7 @@ template <typename T> static bool use_gemm2() {
 
 template <typename T>
 hipError_t gemm_nt(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int I, int J, int Kd,
-                   hipStream_t s, T* scratch, size_t scratch_elems, int* splits_out) {
+                   hipStream_t s, T* scratch, size_t scratch_elems, int* splits_out, int j_valid) {
     if (splits_out) *splits_out = 0;
     if (I <= 0 || J <= 0) return hipSuccess;
     if (use_gemm2<T>() && gemm2_ok<T>(L, ldl, R, ldr, C, ldc, I, J, Kd)) {
@@ -197,7 +202,7 @@ hipError_t gemm_nt(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int 
         if (scratch && (hipGetDevice(&dev) != hipSuccess ||
                         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess))
             cus = 0;
-        return gemm2<T>(L, ldl, R, ldr, C, ldc, I, J, Kd, s, scratch, scratch_elems, splits_out, cus);
+        return gemm2<T>(L, ldl, R, ldr, C, ldc, I, J, Kd, s, scratch, scratch_elems, splits_out, cus, j_valid);
     }
     if (I % 128 || J % 64 || Kd % KS || Kd <= 0) return hipErrorInvalidValue;
     MuEpilogue<T> ep{};
@@ -216,8 +221,8 @@ hipError_t gemm_nt(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int 
                 if (nslabs % sp == 0 && blocks * sp <= 1024 && Kd / sp >= chunk && (size_t)sp * slab <= scratch_elems)
                     splits = sp;
         }
-        if (splits == 1) return launch_nt<T, 64, 64, 32, 32, false>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s);
-        hipError_t e = launch_nt<T, 64, 64, 32, 32, false>(L, ldl, R, ldr, scratch, ldc, I, J, Kd, ep, s, splits, slab);
+        if (splits == 1) return launch_nt<T, 64, 64, 32, 32, false>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s, 1, 0, j_valid);
+        hipError_t e = launch_nt<T, 64, 64, 32, 32, false>(L, ldl, R, ldr, scratch, ldc, I, J, Kd, ep, s, splits, slab, j_valid);
         if (e != hipSuccess) return e;
         if (splits_out) {      // the caller's next kernel sums the slabs itself (scratch + z * I * ldc, z < splits)
             *splits_out = splits;
@@ -227,8 +232,8 @@ hipError_t gemm_nt(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int 
                            slab, C);
         return hipGetLastError();
     }
-    if (J % 128 == 0) return launch_nt<T, 128, 128, 64, 32, false>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s);
-    return launch_nt<T, 128, 64, 32, 32, false>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s);
+    if (J % 128 == 0) return launch_nt<T, 128, 128, 64, 32, false>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s, 1, 0, j_valid);
+    return launch_nt<T, 128, 64, 32, 32, false>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s, 1, 0, j_valid);
 }
 
 template <typename T>
@@ -419,7 +424,7 @@ hipError_t synth_skinny(const T* H, long hst, long hsn, const T* B, long bsn, lo
 }
 
 #define EVC_INST(T)                                                                                  \
-    template hipError_t gemm_nt<T>(const T*, int, const T*, int, T*, int, int, int, int, hipStream_t, T*, size_t, int*); \
+    template hipError_t gemm_nt<T>(const T*, int, const T*, int, T*, int, int, int, int, hipStream_t, T*, size_t, int*, int); \
     template hipError_t gemm_nt_mu<T>(const T*, int, const T*, int, T*, int, int, int,                \
                                       const MuEpilogue<T>&, hipStream_t);                            \
     template hipError_t sum_slabs<T>(const T*, long, int, T*, hipStream_t);                          \

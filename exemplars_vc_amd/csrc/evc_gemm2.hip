@@ -15,8 +15,11 @@
 //     one 16- or 32-byte access per lane and tile;
 //   * a single tile shape and no look at how the grid fills 256 CUs -> shapes and split-K chosen per call.
 #include "evc_internal.h"
+#include <type_traits>
 
 namespace evc {
+
+constexpr int EPI_KL = 100, EPI_STORE = 101;      // epilogue bodies besides the four eps modes
 
 template <typename T> struct G2T;
 template <> struct G2T<double> { typedef double vec __attribute__((ext_vector_type(2))); typedef double vec4 __attribute__((ext_vector_type(4))); };
@@ -27,7 +30,7 @@ template <> struct G2T<float> { typedef float vec __attribute__((ext_vector_type
 template <typename T, int BF, int BR, int WF, int WR, int BK, bool MU, int MINW, int DEPTH>
 __global__ __launch_bounds__((BF / WF) * (BR / WR) * 64, MINW) void k_gemm2(
     const T* __restrict__ L, int ldl, const T* __restrict__ R, int ldr, T* __restrict__ C, int ldc, int Kd,
-    MuEpilogue<T> ep, long slab) {
+    MuEpilogue<T> ep, long slab, int jv) {
     typedef typename Mma<T>::acc_t acc_t;
     typedef typename G2T<T>::vec vec;
     typedef typename G2T<T>::vec4 vec4;
@@ -44,14 +47,33 @@ __global__ __launch_bounds__((BF / WF) * (BR / WR) * 64, MINW) void k_gemm2(
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     T* sm = reinterpret_cast<T*>(smem_raw);               // [DEPTH + 1][ROWS][BK]
 
-    // split-K: blockIdx.z owns k in [z Kd, (z+1) Kd) and writes its partial product to slab z
-    L += (long)blockIdx.z * Kd;
-    R += (long)blockIdx.z * Kd;
-    C += (long)blockIdx.z * slab;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // Block coordinates.  Workgroups go to the 8 XCDs round-robin by linear id, each XCD with its own L2.  The plain
+    // product (V = H Am^T: few R blocks, each frame block's rows of H wanted by all of them) renumbers the grid so
+    // that the R blocks of one frame block are neighbours in time on ONE XCD: H then crosses the fabric once
+    // instead of once per R block.  The update kernel keeps the plain order: there an XCD sees every 8th exemplar
+    // block only, i.e. one eighth of the dictionary, and the shared operand (V) is small.
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (!MU) {
+        const unsigned gx = gridDim.x, gxy = gx * gridDim.y, total = gxy * gridDim.z;
+        const unsigned lin = bx + gx * by + gxy * bz, xcd = lin & 7u;
+        const unsigned v = xcd * (total >> 3) + (xcd < (total & 7u) ? xcd : (total & 7u)) + (lin >> 3);
+        bz = v / gxy;
+        const unsigned rem = v - bz * gxy;
+        by = rem / gx;
+        bx = rem - by * gx;
+    }
+    // split-K: block z owns k in [z Kd, (z+1) Kd) and writes its partial product to slab z
+    L += (long)bz * Kd;
+    R += (long)bz * Kd;
+    C += (long)bz * slab;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wf = w % NWF, wr = w / NWF;
     const int i16 = lane & 15, q = lane >> 4;
-    const long bf0 = (long)blockIdx.y * BF, br0 = (long)blockIdx.x * BR;
+    const long bf0 = (long)by * BF, br0 = (long)bx * BR;
+    // rows of R at and beyond jv are zero padding (the bins of V = H Am^T rounded up to the block width): their
+    // 16-row groups are not multiplied - the wavefront's matrix-pipe time goes to the CU's other workgroups
+    int nri = ((int)(jv - (br0 + wr * WR)) + 15) / 16;
+    nri = nri < 0 ? 0 : (nri > RI ? RI : nri);
 
     if (MU) {
         // a block whose frames all belong to stopped utterances only carries H over
@@ -144,7 +166,7 @@ __global__ __launch_bounds__((BF / WF) * (BR / WR) * 64, MINW) void k_gemm2(
                 vec fa[RI], fb[FI];
 #pragma unroll
                 for (int ri = 0; ri < RI; ++ri)
-                    fa[ri] = *reinterpret_cast<const vec*>(b + rowA[ri] * BK + ((4 * kk + q) ^ keyA) * EPV);
+                    if (ri < nri) fa[ri] = *reinterpret_cast<const vec*>(b + rowA[ri] * BK + ((4 * kk + q) ^ keyA) * EPV);
 #pragma unroll
                 for (int fi = 0; fi < FI; ++fi)
                     fb[fi] = *reinterpret_cast<const vec*>(b + rowB[fi] * BK + ((4 * kk + q) ^ keyB) * EPV);
@@ -152,8 +174,10 @@ __global__ __launch_bounds__((BF / WF) * (BR / WR) * 64, MINW) void k_gemm2(
                 for (int e = 0; e < EPV; ++e)
 #pragma unroll
                     for (int ri = 0; ri < RI; ++ri)
+                        if (ri < nri) {
 #pragma unroll
-                        for (int fi = 0; fi < FI; ++fi) acc[ri][fi] = Mma<T>::mma(fa[ri][e], fb[fi][e], acc[ri][fi]);
+                            for (int fi = 0; fi < FI; ++fi) acc[ri][fi] = Mma<T>::mma(fa[ri][e], fb[fi][e], acc[ri][fi]);
+                        }
             }
         }
     };
@@ -191,48 +215,74 @@ __global__ __launch_bounds__((BF / WF) * (BR / WR) * 64, MINW) void k_gemm2(
         }
     }
 
-    // epilogue: lane (i16, q) holds, per tile, rows 4 q .. 4 q + 3 of R (consecutive columns of C) of frame i16
+    // epilogue: lane (i16, q) holds, per tile, rows 4 q .. 4 q + 3 of R (consecutive columns of C) of frame i16.
+    // The guard mode is a template argument of the epilogue body: one uniform switch in front of it instead of one
+    // per element (which left 650 basic blocks and each element's division chain on its own), a stopped frame is a
+    // select, and the zero padding of the last exemplar block a wave-uniform case.
+    auto epilogue_body = [&](auto mode_tag, auto edge_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;          // eps mode; EPI_KL; EPI_STORE
+        constexpr bool edge = decltype(edge_tag)::value;         // the block reaches into the zero padding of H
 #pragma unroll
-    for (int fi = 0; fi < FI; ++fi) {
-        const long t = bf0 + wf * WF + 16 * fi + i16;
-        bool live = true;
-        if (MU) {
-            const int u = ep.frame_utt[t];
-            live = (u >= 0) && (ep.active[u] != 0);
-        }
-#pragma unroll
-        for (int ri = 0; ri < RI; ++ri) {
-            const long n0 = br0 + wr * WR + 16 * ri + 4 * q;
-            vec4 out;
+        for (int fi = 0; fi < FI; ++fi) {
+            const long t = bf0 + wf * WF + 16 * fi + i16;
+            bool live = true;
             if (MU) {
-                const vec4 h = PREF ? hv[PREF ? ri : 0][PREF ? fi : 0] : *reinterpret_cast<const vec4*>(ep.Hin + t * ep.ldh + n0);
-                out = h;
-                if (live) {
-                    if (ep.kl) {
+                const int u = ep.frame_utt[t];
+                live = (u >= 0) && (ep.active[u] != 0);
+            }
+#pragma unroll
+            for (int ri = 0; ri < RI; ++ri) {
+                const long n0 = br0 + wr * WR + 16 * ri + 4 * q;
+                vec4 out;
+                if (MODE == EPI_STORE) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) out[r] = acc[ri][fi][r];
+                } else {
+                    const vec4 h = PREF ? hv[PREF ? ri : 0][PREF ? fi : 0]
+                                        : *reinterpret_cast<const vec4*>(ep.Hin + t * ep.ldh + n0);
+                    if (MODE == EPI_KL) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) out[r] = h[r] * acc[ri][fi][r];
                     } else {
-                        const vec4 p = PREFP ? pv[PREFP ? ri : 0][PREFP ? fi : 0] : *reinterpret_cast<const vec4*>(ep.P + t * ep.ldh + n0);
+                        const vec4 p = PREFP ? pv[PREFP ? ri : 0][PREFP ? fi : 0]
+                                             : *reinterpret_cast<const vec4*>(ep.P + t * ep.ldh + n0);
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            out[r] = mu_update<T>(h[r], p[r], acc[ri][fi][r], ep.eps_mode, ep.eps, ep.l1);
+                            out[r] = mu_update<T>(h[r], p[r], acc[ri][fi][r], MODE, ep.eps, ep.l1);
+                    }
+                    if (edge) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (n0 + r >= ep.N) out[r] = T(0);   // keep the zero padding exact (0/0 modes)
                     }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (n0 + r >= ep.N) out[r] = T(0);       // keep the zero padding exact (0/0 modes)
+                    for (int r = 0; r < 4; ++r) out[r] = live ? out[r] : h[r];
                 }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) out[r] = acc[ri][fi][r];
+                *reinterpret_cast<vec4*>(C + t * ldc + n0) = out;
             }
-            *reinterpret_cast<vec4*>(C + t * ldc + n0) = out;
+        }
+    };
+    auto epilogue = [&](auto mode_tag) {
+        if (MU && br0 + BR > ep.N) epilogue_body(mode_tag, std::true_type{});
+        else epilogue_body(mode_tag, std::false_type{});
+    };
+    if (!MU) {
+        epilogue(std::integral_constant<int, EPI_STORE>{});
+    } else if (ep.kl) {
+        epilogue(std::integral_constant<int, EPI_KL>{});
+    } else {
+        switch (ep.eps_mode) {
+            case EVC_EPS_ADD: epilogue(std::integral_constant<int, EVC_EPS_ADD>{}); break;
+            case EVC_EPS_ZERO_REPLACE: epilogue(std::integral_constant<int, EVC_EPS_ZERO_REPLACE>{}); break;
+            case EVC_EPS_CLAMP: epilogue(std::integral_constant<int, EVC_EPS_CLAMP>{}); break;
+            default: epilogue(std::integral_constant<int, EVC_EPS_NONE>{}); break;
         }
     }
 }
 
 template <typename T, int BF, int BR, int WF, int WR, int BK, bool MU, int MINW, int DEPTH = 1>
 static hipError_t launch2(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int I, int J, int Kd,
-                          const MuEpilogue<T>& ep, hipStream_t s, int splits = 1, long slab = 0) {
+                          const MuEpilogue<T>& ep, hipStream_t s, int splits = 1, long slab = 0, int jv = 0) {
     constexpr int NTHR = (BF / WF) * (BR / WR) * 64;
     const size_t lds = (size_t)(DEPTH + 1) * (BF + BR) * BK * sizeof(T);
     if (lds > 64 * 1024) {
@@ -242,7 +292,7 @@ static hipError_t launch2(const T* L, int ldl, const T* R, int ldr, T* C, int ld
     }
     dim3 grid(J / BR, I / BF, splits), block(NTHR);
     hipLaunchKernelGGL((k_gemm2<T, BF, BR, WF, WR, BK, MU, MINW, DEPTH>), grid, block, lds, s, L, ldl, R, ldr, C, ldc,
-                       Kd / splits, ep, slab);
+                       Kd / splits, ep, slab, jv > 0 ? jv : J);
     return hipGetLastError();
 }
 
@@ -267,12 +317,12 @@ template <typename T> struct G2K { static constexpr int BIG = 256 / (int)sizeof(
 //   SMALL64 64 x  64, 256,  48 KiB, 3 (two slabs in flight)  R with a multiple of 64 (not 128) rows: V = H Am^T for M <= 64 mod 128
 template <typename T, bool MU>
 static hipError_t launch_shape(int shape, const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int I, int J, int Kd,
-                               const MuEpilogue<T>& ep, hipStream_t s, int splits, long slab) {
+                               const MuEpilogue<T>& ep, hipStream_t s, int splits, long slab, int jv = 0) {
     switch (shape) {
-        case 0: return launch2<T, 128, 128, 32, 64, G2K<T>::BIG, MU, 2>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s, splits, slab);
-        case 1: return launch2<T, 128, 128, 32, 64, G2K<T>::SMALL, MU, sizeof(T) == 4 ? 4 : 2>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s, splits, slab);
-        case 2: return launch2<T, 64, 128, 32, 64, G2K<T>::SMALL, MU, 3>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s, splits, slab);
-        default: return launch2<T, 64, 64, 32, 32, G2K<T>::SMALL, MU, 3, 2>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s, splits, slab);
+        case 0: return launch2<T, 128, 128, 32, 64, G2K<T>::BIG, MU, 2>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s, splits, slab, jv);
+        case 1: return launch2<T, 128, 128, 32, 64, G2K<T>::SMALL, MU, sizeof(T) == 4 ? 4 : 2>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s, splits, slab, jv);
+        case 2: return launch2<T, 64, 128, 32, 64, G2K<T>::SMALL, MU, 3>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s, splits, slab, jv);
+        default: return launch2<T, 64, 64, 32, 32, G2K<T>::SMALL, MU, 3, 2>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s, splits, slab, jv);
     }
 }
 
@@ -281,7 +331,7 @@ static double round_eff(long wg, long slots) { return (double)wg / (double)(((wg
 // C = L R^T.  With `scratch` (and ldc == J) a short grid is split over k into slabs; see gemm_nt for splits_out.
 template <typename T>
 hipError_t gemm2(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int I, int J, int Kd, hipStream_t s,
-                 T* scratch, size_t scratch_elems, int* splits_out, int n_cus) {
+                 T* scratch, size_t scratch_elems, int* splits_out, int n_cus, int jv) {
     if (splits_out) *splits_out = 0;
     MuEpilogue<T> ep{};
     if (n_cus <= 0) n_cus = 256;
@@ -291,6 +341,8 @@ hipError_t gemm2(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int I,
     const bool wide = J % 128 == 0 && (long)(I / 64) * (J / 128) >= 3L * n_cus;
     const int shape = wide ? 2 : 3;
     const long blocks = (long)(I / 64) * (J / (wide ? 128 : 64));
+    // (48 KiB of LDS hold three workgroups per CU for either shape; counting four for the narrow one makes the rule
+    // split a little earlier, which measured better: STFT flow, 16 utterances, 157.8 against 155.5 kframes/s)
     const long slots = (long)n_cus * (wide ? 3 : 4);
     // split-K so that the grid fills the CUs' workgroup slots in whole rounds: the smallest split whose rounds
     // are >= 85 % full (each workgroup keeps >= 128 of k)
@@ -305,7 +357,7 @@ hipError_t gemm2(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int I,
         }
     }
     T* out = splits > 1 ? scratch : C;
-    hipError_t e = launch_shape<T, false>(shape, L, ldl, R, ldr, out, ldc, I, J, Kd, ep, s, splits, slab);
+    hipError_t e = launch_shape<T, false>(shape, L, ldl, R, ldr, out, ldc, I, J, Kd, ep, s, splits, slab, jv);
     if (e != hipSuccess || splits == 1) return e;
     if (splits_out) {          // the caller's next kernel sums the slabs itself (scratch + z * I * ldc, z < splits)
         *splits_out = splits;
@@ -336,7 +388,7 @@ hipError_t gemm2_mu(const T* L, int ldl, const T* R, int ldr, T* Hout, int I, in
 #define EVC_INST2(T)                                                                                              \
     template bool gemm2_ok<T>(const T*, int, const T*, int, const T*, int, int, int, int);                        \
     template hipError_t gemm2<T>(const T*, int, const T*, int, T*, int, int, int, int, hipStream_t, T*, size_t,  \
-                                 int*, int);                                                                       \
+                                 int*, int, int);                                                                   \
     template hipError_t gemm2_mu<T>(const T*, int, const T*, int, T*, int, int, int, const MuEpilogue<T>&, hipStream_t);
 EVC_INST2(double)
 EVC_INST2(float)

@@ -85,7 +85,9 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 // scratch (optional, scratch_elems elements): lets a small-grid, long-K product be split over K.
 template <typename T>
 hipError_t gemm_nt(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int I, int J, int Kd,
-                   hipStream_t s, T* scratch = nullptr, size_t scratch_elems = 0, int* splits_out = nullptr);
+                   hipStream_t s, T* scratch = nullptr, size_t scratch_elems = 0, int* splits_out = nullptr,
+                   int j_valid = 0);
+// j_valid: rows of R from j_valid on are known to be zero (padding up to the block width); their products are skipped
 // splits_out: when the contraction was split over k into slabs in `scratch` (slab z at scratch + z * I * ldc),
 // *splits_out = their number and C is NOT written - the caller's next kernel sums them in order; else 0.
 // Same contraction with the multiplicative update as epilogue: C = mu(Hin, P, L R^T).
@@ -98,7 +100,7 @@ template <typename T>
 bool gemm2_ok(const T* L, int ldl, const T* R, int ldr, const T* C, int ldc, int I, int J, int Kd);
 template <typename T>
 hipError_t gemm2(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int I, int J, int Kd, hipStream_t s,
-                 T* scratch, size_t scratch_elems, int* splits_out, int n_cus);
+                 T* scratch, size_t scratch_elems, int* splits_out, int n_cus, int j_valid);
 template <typename T>
 hipError_t gemm2_mu(const T* L, int ldl, const T* R, int ldr, T* Hout, int I, int J, int Kd,
                     const MuEpilogue<T>& ep, hipStream_t s);
