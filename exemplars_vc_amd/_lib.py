@@ -24,7 +24,8 @@ FLAG_NO_FUSED, FLAG_EXACT_DIV, FLAG_NO_EXCHANGE, FLAG_NO_ALL_RESIDENT = 1, 2, 4,
 # every symbol include/evc.h declares; tests check that the library exports all of them
 SYMBOLS = ("evc_version", "evc_strerror", "evc_device_count", "evc_workspace_bytes",
            "evc_nmf_solve", "evc_nmf_convert", "evc_synthesize", "evc_residual",
-           "evc_griffin_lim_workspace_bytes", "evc_griffin_lim", "evc_dtw_workspace_bytes", "evc_dtw_align",
+           "evc_griffin_lim_workspace_bytes", "evc_griffin_lim", "evc_griffin_lim_batch_workspace_bytes",
+           "evc_griffin_lim_batch", "evc_dtw_workspace_bytes", "evc_dtw_align",
            "evc_stft_frames", "evc_stft_workspace_bytes", "evc_stft")
 
 
@@ -99,6 +100,11 @@ def lib():
     L.evc_griffin_lim.restype = C.c_int
     L.evc_griffin_lim.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                   C.c_void_p, C.c_size_t, C.POINTER(C.c_double), C.c_void_p]
+    L.evc_griffin_lim_batch_workspace_bytes.restype = C.c_size_t
+    L.evc_griffin_lim_batch_workspace_bytes.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int]
+    L.evc_griffin_lim_batch.restype = C.c_int
+    L.evc_griffin_lim_batch.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_double), C.c_void_p]
     L.evc_stft_frames.restype = C.c_int
     L.evc_stft_frames.argtypes = [C.c_long, C.c_int, C.c_int, C.c_int]
     L.evc_stft_workspace_bytes.restype = C.c_size_t

@@ -646,17 +646,43 @@ int evc_residual(const void* A, int lda, const void* X, int ldx, const void* H, 
 
 size_t evc_griffin_lim_workspace_bytes(int T, int fft_size, int hop, int iters) {
     if (T < 1 || fft_size < 2 || (fft_size & 1) || hop < 1 || iters < 0) return 0;
-    return gl_workspace_bytes(T, fft_size, hop, iters);
+    return gl_workspace_bytes(T, 1, fft_size, hop, iters);
 }
 
 int evc_griffin_lim(const void* mag, int ldm, int T, int fft_size, int hop, int iters, void* x,
                     void* workspace, size_t workspace_bytes, double* rmse_out, evc_stream_t stream) {
-    if (T < 0 || fft_size < 2 || (fft_size & 1) || hop < 1 || iters < 0) return ST_BADARG;
-    if (T == 0) return ST_OK;
+    if (T < 0) return ST_BADARG;
+    const int off[2] = {0, T};
+    return evc_griffin_lim_batch(mag, ldm, off, 1, fft_size, hop, iters, x, workspace, workspace_bytes, rmse_out,
+                                 stream);
+}
+
+static bool gl_offsets_ok(const int* off, int n_utt) {
+    if (!off || n_utt < 1 || off[0] != 0) return false;
+    for (int u = 0; u < n_utt; ++u)
+        if (off[u + 1] < off[u]) return false;
+    return true;
+}
+
+size_t evc_griffin_lim_batch_workspace_bytes(const int* frame_offsets, int n_utt, int fft_size, int hop, int iters) {
+    if (!gl_offsets_ok(frame_offsets, n_utt) || frame_offsets[n_utt] < 1 || fft_size < 2 || (fft_size & 1) ||
+        hop < 1 || iters < 0)
+        return 0;
+    return gl_workspace_bytes(frame_offsets[n_utt], n_utt, fft_size, hop, iters);
+}
+
+int evc_griffin_lim_batch(const void* mag, int ldm, const int* frame_offsets, int n_utt, int fft_size, int hop,
+                          int iters, void* x, void* workspace, size_t workspace_bytes, double* rmse_out,
+                          evc_stream_t stream) {
+    if (!gl_offsets_ok(frame_offsets, n_utt) || fft_size < 2 || (fft_size & 1) || hop < 1 || iters < 0)
+        return ST_BADARG;
+    if (frame_offsets[n_utt] == 0) return ST_OK;
     if (!mag || !x || !workspace || ldm < fft_size / 2 + 1) return ST_BADARG;
-    if (workspace_bytes < gl_workspace_bytes(T, fft_size, hop, iters)) return ST_WORKSPACE;
-    return (int)gl_run(static_cast<const double*>(mag), ldm, T, fft_size, hop, iters, static_cast<double*>(x),
-                       workspace, rmse_out, reinterpret_cast<hipStream_t>(stream));
+    const size_t need = gl_workspace_bytes(frame_offsets[n_utt], n_utt, fft_size, hop, iters);
+    if (need == 0) return ST_BADARG;
+    if (workspace_bytes < need) return ST_WORKSPACE;
+    return (int)gl_run(static_cast<const double*>(mag), ldm, frame_offsets, n_utt, fft_size, hop, iters,
+                       static_cast<double*>(x), workspace, rmse_out, reinterpret_cast<hipStream_t>(stream));
 }
 
 int evc_stft_frames(long n_samples, int fft_size, int hop, int center) {
@@ -698,6 +724,7 @@ int evc_dtw_align(const void* A, int lda, const int* a_offsets, const void* B, i
                   const int* b_offsets, int D, int n_pairs, int* path_a, int* path_b, int* path_len,
                   double* total, void* workspace, size_t workspace_bytes, evc_stream_t stream) {
     if (n_pairs < 1 || D < 1 || lda < D || ldb < D) return ST_BADARG;
+    if (D > 512 || n_pairs > 65535) return ST_UNSUPPORTED;     // LDS tile of the cost kernel; grid z
     if (!dtw_offsets_ok(a_offsets, n_pairs) || !dtw_offsets_ok(b_offsets, n_pairs)) return ST_BADARG;
     if (!A || !B || !path_a || !path_b || !path_len || !workspace) return ST_BADARG;
     if (workspace_bytes < dtw_workspace_bytes(a_offsets, b_offsets, n_pairs)) return ST_WORKSPACE;

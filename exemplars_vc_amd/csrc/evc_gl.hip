@@ -1,6 +1,6 @@
 // Griffin-Lim phase reconstruction: the back end that follows the activation solve when
 // the scripts run on STFT magnitudes (04_align_n_nmf.py:182-191 -> zz_audio_utilities.py:181-218,
-// 258-292).  float64, one utterance per call.
+// 258-292).  float64; one utterance or a batch of them per call.
 //
 // With fft_size = 400 (not a power of two) and a few hundred frames, the transforms are small dense
 // contractions, so both directions run on the fp64 matrix cores through k_gemm_nt:
@@ -9,6 +9,14 @@
 //   x' = overlap_add(P W_i)   W_i = irfft basis (DC/Nyquist weight 1, others 2, /fft_size) (.) hanning
 // Between them one small kernel replaces magnitudes (P = mag * exp(j angle(S))), after them one
 // gathers the overlap-add (each sample sums its <= fft/hop frames in frame order: deterministic).
+//
+// Batch: one utterance is 688 frames x 400 samples - 84 output tiles, a third of the CUs, 5 launches of ~20 us per
+// iteration.  A batch is laid out as ONE virtual signal: utterance u starts at virtual frame row
+// r_u = frame_offsets[u] + u G, G = ceil(fft / hop), i.e. at sample hop r_u, so that the frames of all utterances
+// are still rows of one strided matrix (row stride hop).  The G rows between two utterances straddle both signals:
+// their magnitudes are taken as zero, so they add nothing to the overlap-add, and the samples between two signals
+// stay zero.  Every kernel below then works on the batch as on one long utterance (0.7 % more rows for 688-frame
+// utterances), and the contractions have thousands of rows.
 #include "evc_internal.h"
 
 namespace evc {
@@ -72,13 +80,14 @@ __global__ __launch_bounds__(256) void k_gl_tables(GlDims d, double* __restrict_
 // S may arrive as `splits` k-slabs (slab z at S + z * slab) that are summed here, in order
 __global__ __launch_bounds__(256) void k_gl_project(const double* __restrict__ S, int lds_, long slab, int splits,
                                                     const double* __restrict__ mag, long ldm, GlDims d,
-                                                    double* __restrict__ P) {
+                                                    const int* __restrict__ row_src, double* __restrict__ P) {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (long)d.Tp * d.K2) return;
     const long t = gid / d.K2;
     const int c = (int)(gid % d.K2);
     double v = 0.0;
-    if (t < d.T_ && c < 2 * d.nb) {
+    const int src = t < d.T_ ? row_src[t] : -1;       // the row of `mag` behind virtual row t (-1: between utterances)
+    if (src >= 0 && c < 2 * d.nb) {
         const int k = c < d.nb ? c : c - d.nb;
         double re = S[t * lds_ + k], im = S[t * lds_ + d.nb + k];
         for (int z = 1; z < splits; ++z) {
@@ -86,7 +95,7 @@ __global__ __launch_bounds__(256) void k_gl_project(const double* __restrict__ S
             im += S[z * slab + t * lds_ + d.nb + k];
         }
         const double ang = atan2(im, re);
-        v = mag[t * ldm + k] * (c < d.nb ? cos(ang) : sin(ang));
+        v = mag[(long)src * ldm + k] * (c < d.nb ? cos(ang) : sin(ang));
     }
     P[gid] = v;
 }
@@ -111,41 +120,78 @@ __global__ __launch_bounds__(256) void k_gl_overlap_add(const double* __restrict
     xn[s] = acc;                                      // zero beyond the signal: the padded GEMM rows read it
 }
 
-// rmse = sqrt(sum((x' - x)^2) / L)   (zz_audio_utilities.py:289); single block, fixed order
-__global__ __launch_bounds__(256) void k_gl_rmse(const double* __restrict__ xn, const double* __restrict__ xo, long L,
+// virtual frame row / sample position of utterance u (G gap rows in front of every utterance but the first)
+__device__ __forceinline__ long gl_row0(const int* off, int u, int G) { return (long)off[u] + (long)u * G; }
+
+// row_src[r] = row of `mag` behind virtual row r, or -1
+__global__ __launch_bounds__(256) void k_gl_rows(const int* __restrict__ off, int n_utt, int G, int Tp,
+                                                 int* __restrict__ row_src) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= Tp) return;
+    int src = -1;
+    for (int u = 0; u < n_utt; ++u) {
+        const long r0 = gl_row0(off, u, G);
+        if (r >= r0 && r < r0 + (off[u + 1] - off[u])) src = off[u] + (int)(r - r0);
+    }
+    row_src[r] = src;
+}
+
+// rmse[u] = sqrt(sum((x' - x)^2) / L_u) over utterance u's samples (zz_audio_utilities.py:289); one block per
+// utterance, fixed order
+__global__ __launch_bounds__(256) void k_gl_rmse(const double* __restrict__ xn, const double* __restrict__ xo,
+                                                 const int* __restrict__ off, int G, int hop, int F, int iters,
                                                  double* __restrict__ out) {
     __shared__ double red[4];
+    const int u = blockIdx.x;
+    const long s0 = gl_row0(off, u, G) * hop, L = (long)(off[u + 1] - off[u]) * hop + F;
     double acc = 0.0;
     for (long s = threadIdx.x; s < L; s += 256) {
-        const double df = xn[s] - xo[s];
+        const double df = xn[s0 + s] - xo[s0 + s];
         acc += df * df;
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) *out = sqrt((red[0] + red[1] + red[2] + red[3]) / (double)L);
+    if (threadIdx.x == 0) out[(long)u * iters] = sqrt((red[0] + red[1] + red[2] + red[3]) / (double)L);
 }
 
-__global__ __launch_bounds__(256) void k_gl_load_x(const double* __restrict__ x0, long L, long Lp, double* __restrict__ xb) {
+// caller's concatenated signals (utterance u at sample hop off[u] + u F) <-> the virtual signal; one block row per
+// utterance.  to_virtual: xv must have been zeroed (the samples between utterances stay zero).
+__global__ __launch_bounds__(256) void k_gl_move_x(double* __restrict__ xc, double* __restrict__ xv,
+                                                   const int* __restrict__ off, int G, int hop, int F, bool to_virtual) {
+    const int u = blockIdx.y;
+    const long L = (long)(off[u + 1] - off[u]) * hop + F;
     const long s = (long)blockIdx.x * 256 + threadIdx.x;
-    if (s < Lp) xb[s] = s < L ? x0[s] : 0.0;
+    if (s >= L) return;
+    const long c = (long)off[u] * hop + (long)u * F + s, v = gl_row0(off, u, G) * hop + s;
+    if (to_virtual) xv[v] = xc[c];
+    else xc[c] = xv[v];
 }
 
-size_t gl_workspace_bytes(int T_, int F, int hop, int iters) {
-    const GlDims d = gl_dims(T_, F, hop);
+static int gl_gap(int F, int hop) { return (F + hop - 1) / hop; }
+// virtual rows of a batch whose utterances hold T_total frames
+static long gl_virtual_rows(long T_total, int n_utt, int F, int hop) { return T_total + (long)(n_utt - 1) * gl_gap(F, hop); }
+
+size_t gl_workspace_bytes(long T_total, int n_utt, int F, int hop, int iters) {
+    const long R = gl_virtual_rows(T_total, n_utt, F, hop);
+    if (R > (1L << 30)) return 0;
+    const GlDims d = gl_dims((int)R, F, hop);
     size_t n = (size_t)d.J1 * d.K1 + (size_t)d.J2 * d.K2       // tables
              + (size_t)d.Tp * d.J1 + (size_t)d.Tp * d.K2 + (size_t)d.Tp * d.J2   // S, P, Fr
-             + 2 * (size_t)d.Lp + (size_t)(iters > 0 ? iters : 1)                 // x ping-pong, rmse trace
-             + 8 * (size_t)d.Tp * (d.J1 > d.J2 ? d.J1 : d.J2);                    // split-K slabs of the contractions
-    return n * sizeof(double) + 10 * 256;
+             + 2 * (size_t)d.Lp + (size_t)(iters > 0 ? iters : 1) * n_utt        // x ping-pong, rmse trace
+             + 8 * (size_t)d.Tp * (d.J1 > d.J2 ? d.J1 : d.J2)                     // split-K slabs of the contractions
+             + ((size_t)d.Tp + n_utt + 1 + 1) / 2;                                // row map, offsets (ints)
+    return n * sizeof(double) + 12 * 256;
 }
 
-// x: in = initial signal (the reference draws randn), out = reconstruction; length T*hop + F.
-// rmse_dev (device, iters doubles, may be NULL): per-iteration sqrt(mean((x_new - x_old)^2)).
-hipError_t gl_run(const double* mag, long ldm, int T_, int F, int hop, int iters, double* x, void* ws,
-                  double* rmse_host, hipStream_t s) {
-    const GlDims d = gl_dims(T_, F, hop);
+// x: the utterances' signals back to back (utterance u: T_u hop + F samples at offset hop off[u] + u F); in = initial
+// signals (the reference draws randn), out = reconstructions.  off: host, n_utt + 1 frame offsets into `mag`.
+// rmse_host (host, [n_utt][iters], may be NULL): per-iteration sqrt(mean((x_new - x_old)^2)) of every utterance.
+hipError_t gl_run(const double* mag, long ldm, const int* off, int n_utt, int F, int hop, int iters, double* x,
+                  void* ws, double* rmse_host, hipStream_t s) {
+    const int G = gl_gap(F, hop);
+    const GlDims d = gl_dims((int)gl_virtual_rows(off[n_utt], n_utt, F, hop), F, hop);
     double* p = static_cast<double*>(ws);
     auto take = [&](size_t n) { double* q = p; p += (n + 31) & ~size_t(31); return q; };
     double* Wf = take((size_t)d.J1 * d.K1);
@@ -155,14 +201,24 @@ hipError_t gl_run(const double* mag, long ldm, int T_, int F, int hop, int iters
     double* Fr = take((size_t)d.Tp * d.J2);
     double* xa = take((size_t)d.Lp);
     double* xb = take((size_t)d.Lp);
-    double* tr = take((size_t)(iters > 0 ? iters : 1));
+    double* tr = take((size_t)(iters > 0 ? iters : 1) * n_utt);
     const size_t nsplit = 8 * (size_t)d.Tp * (d.J1 > d.J2 ? d.J1 : d.J2);
     double* split = take(nsplit);
+    int* doff = reinterpret_cast<int*>(take(((size_t)n_utt + 2) / 2));
+    int* row_src = reinterpret_cast<int*>(take(((size_t)d.Tp + 1) / 2));
 
+    hipError_t e = hipMemcpyAsync(doff, off, sizeof(int) * (n_utt + 1), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(xa, 0, sizeof(double) * d.Lp, s);
+    if (e != hipSuccess) return e;
+    int Tmax = 0;
+    for (int u = 0; u < n_utt; ++u) Tmax = off[u + 1] - off[u] > Tmax ? off[u + 1] - off[u] : Tmax;
+    const dim3 mv_grid((unsigned)(((long)Tmax * hop + F + 255) / 256), (unsigned)n_utt);
     const long nt = (long)d.J1 * d.K1 + (long)d.J2 * d.K2;
     hipLaunchKernelGGL(k_gl_tables, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, d, Wf, Wi, false);
-    hipLaunchKernelGGL(k_gl_load_x, dim3((unsigned)((d.Lp + 255) / 256)), dim3(256), 0, s, x, d.L, d.Lp, xa);
-    hipError_t e = hipGetLastError();
+    hipLaunchKernelGGL(k_gl_rows, dim3((unsigned)((d.Tp + 255) / 256)), dim3(256), 0, s, doff, n_utt, G, d.Tp, row_src);
+    hipLaunchKernelGGL(k_gl_move_x, mv_grid, dim3(256), 0, s, x, xa, doff, G, hop, F, true);
+    e = hipGetLastError();
     if (e != hipSuccess) return e;
     double* xc = xa;
     double* xn = xb;
@@ -173,18 +229,20 @@ hipError_t gl_run(const double* mag, long ldm, int T_, int F, int hop, int iters
         if (e != hipSuccess) return e;
         const long np_ = (long)d.Tp * d.K2;
         hipLaunchKernelGGL(k_gl_project, dim3((unsigned)((np_ + 255) / 256)), dim3(256), 0, s, sp ? split : S, d.J1,
-                           (long)d.Tp * d.J1, sp ? sp : 1, mag, ldm, d, P);
+                           (long)d.Tp * d.J1, sp ? sp : 1, mag, ldm, d, row_src, P);
         e = gemm_nt<double>(P, d.K2, Wi, d.K2, Fr, d.J2, d.Tp, d.J2, d.K2, s, split, nsplit, &sp);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_gl_overlap_add, dim3((unsigned)((d.Lp + 255) / 256)), dim3(256), 0, s, sp ? split : Fr,
                            d.J2, (long)d.Tp * d.J2, sp ? sp : 1, d, xn);
-        if (rmse_host) hipLaunchKernelGGL(k_gl_rmse, dim3(1), dim3(256), 0, s, xn, xc, d.L, tr + it);
+        if (rmse_host)
+            hipLaunchKernelGGL(k_gl_rmse, dim3((unsigned)n_utt), dim3(256), 0, s, xn, xc, doff, G, hop, F, iters, tr + it);
         double* t = xc; xc = xn; xn = t;
     }
-    e = hipMemcpyAsync(x, xc, sizeof(double) * d.L, hipMemcpyDeviceToDevice, s);
+    hipLaunchKernelGGL(k_gl_move_x, mv_grid, dim3(256), 0, s, x, xc, doff, G, hop, F, false);
+    e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (rmse_host && iters > 0) {
-        e = hipMemcpyAsync(rmse_host, tr, sizeof(double) * iters, hipMemcpyDeviceToHost, s);
+        e = hipMemcpyAsync(rmse_host, tr, sizeof(double) * iters * n_utt, hipMemcpyDeviceToHost, s);
         if (e != hipSuccess) return e;
         e = hipStreamSynchronize(s);
         if (e != hipSuccess) return e;
@@ -217,15 +275,21 @@ __global__ __launch_bounds__(256) void k_stft_pad(const double* __restrict__ x, 
     xp[i] = v;
 }
 
-__global__ __launch_bounds__(256) void k_stft_split(const double* __restrict__ S, int lds_, int T_, int nb,
-                                                    double* __restrict__ re, long ldre, double* __restrict__ im,
-                                                    long ldim) {
+// S may arrive as `splits` k-slabs (slab z at S + z * slab) that are summed here, in order
+__global__ __launch_bounds__(256) void k_stft_split(const double* __restrict__ S, int lds_, long slab, int splits,
+                                                    int T_, int nb, double* __restrict__ re, long ldre,
+                                                    double* __restrict__ im, long ldim) {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (long)T_ * nb) return;
     const long t = gid / nb;
     const int k = (int)(gid % nb);
-    re[t * ldre + k] = S[t * lds_ + k];
-    im[t * ldim + k] = S[t * lds_ + nb + k];
+    double r = S[t * lds_ + k], i = S[t * lds_ + nb + k];
+    for (int z = 1; z < splits; ++z) {
+        r += S[z * slab + t * lds_ + k];
+        i += S[z * slab + t * lds_ + nb + k];
+    }
+    re[t * ldre + k] = r;
+    im[t * ldim + k] = i;
 }
 
 int stft_frames(long L, int hop, bool center, int F) {
@@ -242,7 +306,7 @@ static GlDims stft_dims(long L, int F, int hop, bool center) {
 
 size_t stft_workspace_bytes(long L, int F, int hop, bool center) {
     const GlDims d = stft_dims(L, F, hop, center);
-    return ((size_t)d.J1 * d.K1 + (size_t)d.Tp * d.J1 + (size_t)d.Lp + 96) * sizeof(double) + 4 * 256;
+    return ((size_t)d.J1 * d.K1 + 9 * (size_t)d.Tp * d.J1 + (size_t)d.Lp + 128) * sizeof(double) + 4 * 256;
 }
 
 hipError_t stft_run(const double* x, long L, int F, int hop, bool center, double* re, long ldre, double* im,
@@ -255,17 +319,20 @@ hipError_t stft_run(const double* x, long L, int F, int hop, bool center, double
     double* Wf = take((size_t)d.J1 * d.K1);
     double* S = take((size_t)d.Tp * d.J1);
     double* xp = take((size_t)d.Lp);
+    const size_t nsplit = 8 * (size_t)d.Tp * d.J1;     // split-K slabs: one utterance is 84 output tiles on 256 CUs
+    double* split = take(nsplit);
     const long nt = (long)d.J1 * d.K1;
     hipLaunchKernelGGL(k_gl_tables, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, s, d, Wf, (double*)nullptr, true);
     hipLaunchKernelGGL(k_stft_pad, dim3((unsigned)((d.Lp + 255) / 256)), dim3(256), 0, s, x, L, center ? F / 2 : 0,
                        d.Lp, xp);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    e = gemm_nt<double>(xp, hop, Wf, d.K1, S, d.J1, d.Tp, d.J1, d.K1, s);
+    int sp = 0;
+    e = gemm_nt<double>(xp, hop, Wf, d.K1, S, d.J1, d.Tp, d.J1, d.K1, s, split, nsplit, &sp);
     if (e != hipSuccess) return e;
     const long n = (long)T_ * d.nb;
-    hipLaunchKernelGGL(k_stft_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, S, d.J1, T_, d.nb, re, ldre,
-                       im, ldim);
+    hipLaunchKernelGGL(k_stft_split, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, sp ? split : S, d.J1,
+                       (long)d.Tp * d.J1, sp ? sp : 1, T_, d.nb, re, ldre, im, ldim);
     return hipGetLastError();
 }
 

@@ -201,13 +201,13 @@ hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttS
                          double l1, int c_req, int all_live_known, int loss, int exact_div, hipStream_t s);
 
 // ----- evc_gl.hip -----
-size_t gl_workspace_bytes(int T_, int F, int hop, int iters);
+size_t gl_workspace_bytes(long T_total, int n_utt, int F, int hop, int iters);
 int stft_frames(long L, int hop, bool center, int F);
 size_t stft_workspace_bytes(long L, int F, int hop, bool center);
 hipError_t stft_run(const double* x, long L, int F, int hop, bool center, double* re, long ldre, double* im,
                     long ldim, void* ws, hipStream_t s);
-hipError_t gl_run(const double* mag, long ldm, int T_, int F, int hop, int iters, double* x, void* ws,
-                  double* rmse_host, hipStream_t s);
+hipError_t gl_run(const double* mag, long ldm, const int* frame_offsets, int n_utt, int F, int hop, int iters, double* x,
+                  void* ws, double* rmse_host, hipStream_t s);
 
 // ----- evc_dtw.hip -----
 size_t dtw_workspace_bytes(const int* aoff, const int* boff, int n_pairs);

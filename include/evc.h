@@ -215,6 +215,20 @@ int evc_stft(const void* x, long n_samples, int fft_size, int hop, int center, v
 size_t evc_griffin_lim_workspace_bytes(int T, int fft_size, int hop, int iters);
 int evc_griffin_lim(const void* mag, int ldm, int T, int fft_size, int hop, int iters, void* x,
                     void* workspace, size_t workspace_bytes, double* rmse_out, evc_stream_t stream);
+/* The same for a batch of utterances in one call (the reference reconstructs one file per call of
+ * synthesize2(), 04_align_n_nmf.py:182-191; a batch fills the GPU, one 688-frame utterance does not).
+ *   frame_offsets : host, n_utt + 1 ints, frame_offsets[0] = 0: utterance u owns rows frame_offsets[u] ..
+ *                   frame_offsets[u+1]-1 of `mag` (T_u frames)
+ *   x             : the signals back to back: utterance u's T_u*hop + fft_size samples start at sample
+ *                   hop*frame_offsets[u] + u*fft_size (device; in: initial signals, out: reconstructions)
+ *   rmse_out      : host, n_utt x iters doubles ([u][iteration]) or NULL; non-NULL makes the call synchronous
+ * Every utterance's result equals that of a call of its own up to the summation order of the contractions
+ * (the split of the 400-deep sums over workgroups depends on the number of rows). */
+size_t evc_griffin_lim_batch_workspace_bytes(const int* frame_offsets, int n_utt, int fft_size, int hop,
+                                             int iters);
+int evc_griffin_lim_batch(const void* mag, int ldm, const int* frame_offsets, int n_utt, int fft_size, int hop,
+                          int iters, void* x, void* workspace, size_t workspace_bytes, double* rmse_out,
+                          evc_stream_t stream);
 
 /* Dynamic-time-warping alignment of parallel utterance pairs - the step that builds the parallel
  * dictionary: _dtw_alignment(), 01_make_dict_parallel.py:215-228, i.e. the third-party call

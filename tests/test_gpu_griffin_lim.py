@@ -57,3 +57,32 @@ def test_full_utterance_size_and_zero_magnitudes():
     assert np.array_equal(evc.griffin_lim(mag, F, hop, 0, x0), x0)
     with pytest.raises(ValueError):
         evc.griffin_lim(mag[:, :-1], F, hop, 1, x0)
+
+
+def test_batch_of_ragged_utterances_equals_single_calls():
+    """evc_griffin_lim_batch: utterances of different lengths (one shorter than a frame hop group, one silent)
+    laid out as one virtual signal; every result against the single-utterance call and against the oracle."""
+    import exemplars_vc_amd as evc
+    from oracle import evc_oracle as o
+    rng = np.random.default_rng(17)
+    F, hop, K = 400, 80, 10
+    Ts = [688, 1, 216, 3, 945, 64]
+    mags = [rng.random((T, F // 2 + 1)) ** 2 for T in Ts]
+    mags[3][:] = 0.0
+    x0s = [rng.standard_normal(T * hop + F) for T in Ts]
+    outs, rmse = evc.griffin_lim_batch(mags, F, hop, K, x0s, want_rmse=True)
+    assert rmse.shape == (len(Ts), K)
+    for u, T in enumerate(Ts):
+        single, rm = evc.griffin_lim(mags[u], F, hop, K, x0s[u], want_rmse=True)
+        scale = max(np.max(np.abs(single)), 1e-300)
+        assert np.max(np.abs(outs[u] - single)) <= 1e-11 * scale, u
+        np.testing.assert_allclose(rmse[u], rm, rtol=1e-9, atol=1e-300)
+    want, _ = o.griffin_lim(mags[2], F, hop, K, x0s[2])
+    close(outs[2], want)
+    # zero iterations hand the initial signals back; a batch of one is the single call, bit for bit
+    same = evc.griffin_lim_batch(mags, F, hop, 0, x0s)
+    assert all(np.array_equal(a, b) for a, b in zip(same, x0s))
+    one = evc.griffin_lim_batch(mags[:1], F, hop, K, x0s[:1])[0]
+    assert np.array_equal(one, evc.griffin_lim(mags[0], F, hop, K, x0s[0]))
+    with pytest.raises(ValueError):
+        evc.griffin_lim_batch(mags, F, hop, 1, x0s[:-1])
