@@ -43,8 +43,19 @@ def _check_dictionary(W, n_features):
     return W
 
 
+def _exchange_allowed(hint):
+    """hint -> solve_activations(cooperative=...).  "throughput" (default): the solver may use the kernels whose
+    workgroups exchange partial sums through device memory (k_fused_all / cooperative k_fused_res: fastest, but the
+    call then ends with ONE host synchronisation, to learn whether a bounded wait timed out - include/evc.h, "Host
+    synchronisation").  "latency": EVC_FLAG_NO_EXCHANGE - no such kernel, the launch sequence is asynchronous up
+    to the copy of the results (for callers that queue several solves on streams)."""
+    if hint not in ("throughput", "latency"):
+        raise ValueError(f"hint must be 'throughput' or 'latency', got {hint!r}")
+    return hint == "throughput"
+
+
 def _factorize(X, W, beta_loss="kullback-leibler", tol=1e-4, *, device=None, algo="auto",
-               honor_beta_loss=False):
+               honor_beta_loss=False, hint="throughput"):
     """H (N x T) with W.T @ H ~ X.T.  X: (T, M) frames as rows, W: (N, M) exemplars as rows.
 
     As in the reference the Frobenius loss is forced whatever `beta_loss` says, the
@@ -72,14 +83,14 @@ def _factorize(X, W, beta_loss="kullback-leibler", tol=1e-4, *, device=None, alg
     act, info = solve_activations(
         W, X, layout="frame_major", iters=MAX_ITER, eps_mode="zero_replace", init="sklearn",
         check_every=CHECK_EVERY if tol > 0 else 0, stop_rule="sklearn" if tol > 0 else "none",
-        tol=tol, algo=algo, device=device, info=True, loss=loss)
+        tol=tol, algo=algo, device=device, info=True, loss=loss, cooperative=_exchange_allowed(hint))
     if tol > 0 and int(info["n_iter"][0]) == MAX_ITER:
         warnings.warn(f"Maximum number of iterations {MAX_ITER} reached. Increase it to improve "
                       "convergence.", ConvergenceWarning, stacklevel=2)
     return act.T
 
 
-def factorize_utterances(X_list, W, tol=1e-4, *, device=None, algo="auto", max_iter=MAX_ITER):
+def factorize_utterances(X_list, W, tol=1e-4, *, device=None, algo="auto", max_iter=MAX_ITER, hint="throughput"):
     """`_factorize` for many utterances in ONE launch sequence: the frames are concatenated,
     the per-call semantics (initial value, stop test) are applied per utterance on the device.
     Returns a list of (N x T_u) arrays and the per-utterance iteration counts."""
@@ -90,7 +101,7 @@ def factorize_utterances(X_list, W, tol=1e-4, *, device=None, algo="auto", max_i
     act, info = solve_activations(
         W, X, layout="frame_major", iters=max_iter, eps_mode="zero_replace", init="sklearn",
         check_every=CHECK_EVERY if tol > 0 else 0, stop_rule="sklearn" if tol > 0 else "none",
-        tol=tol, algo=algo, device=device, utt_offsets=offs, info=True)
+        tol=tol, algo=algo, device=device, utt_offsets=offs, info=True, cooperative=_exchange_allowed(hint))
     return [act[offs[i]:offs[i + 1]].T for i in range(len(X_list))], info["n_iter"]
 
 
@@ -114,7 +125,7 @@ RESIDUAL_FLOOR = 1e-10   # positive floor of the log-ratio residual (not in the 
 
 
 def factorize(tobe_converted, src_feat, *, use_stft=True, tol=1e-4, device=None, cache_dir=None,
-              cache_key="content", residual="reference"):
+              cache_key="content", residual="reference", hint="throughput"):
     """`factorize(tobe_converted, src_feat)` of 04_align_n_nmf.py:218-333: stack the aligned source
     exemplars into the dictionary, solve the activations of the utterance to convert (one solve per
     feature stream), and - WORLD branch - form the reference's residual.
@@ -134,6 +145,9 @@ def factorize(tobe_converted, src_feat, *, use_stft=True, tol=1e-4, device=None,
     utterance gets the first one's H back; cache_key="content" (default) adds a digest of the
     utterance and the dictionary to the name, cache_key="reference" reproduces the reference's name
     (and its hazard) so that caches written by the reference are found.
+
+    hint: "throughput" (default) or "latency" - see _exchange_allowed(): "latency" keeps the solver to kernels
+    without inter-workgroup exchange, whose launch sequence needs no host synchronisation.
     """
     from . import artifacts
     if use_stft:
@@ -145,7 +159,7 @@ def factorize(tobe_converted, src_feat, *, use_stft=True, tol=1e-4, device=None,
             hpath = artifacts.activation_cache_path(cache_dir, True, len(src_feat), "H", cache_key, dg)
             if os.path.isfile(hpath):
                 return artifacts.read_activations(hpath, True), None
-        H = {"H_stft": _factorize(conv_stft, A_stft, tol=tol, device=device)}
+        H = {"H_stft": _factorize(conv_stft, A_stft, tol=tol, device=device, hint=hint)}
         if hpath is not None:
             artifacts.write_activations(hpath, H)
         return H, None
@@ -165,7 +179,7 @@ def factorize(tobe_converted, src_feat, *, use_stft=True, tol=1e-4, device=None,
                 return H, artifacts.read_residuals(rpath)
     for name, (conv, A) in streams.items():
         if "H_" + name not in H:
-            H["H_" + name] = _factorize(conv, A, tol=tol, device=device)
+            H["H_" + name] = _factorize(conv, A, tol=tol, device=device, hint=hint)
         # a cached H without its R: the residual is recomputed from it (:261-276; the expression there,
         # np.matmul(A, H), has its operands the wrong way round and cannot run - :292-294's is used)
         recon = synthesize_rows(H["H_" + name], A, device=device)

@@ -214,10 +214,13 @@ int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_sol
         fb.coop_c = fused_res_coop_factor(w.fl.NT, w.fl.TT, cus);
     const bool exchanges = fb.coop_c > 1 || fb.all_c > 1;
     int* coop_abort = fb.coop_cnt + COOP_MAX_TILES;
-    // tests only (environment, not part of the ABI): EVC_TEST_COOP_ABORT starts the call with the abort flag raised,
-    // so that it takes the retry path below
-    if (exchanges) HIP_TRY(hipMemsetAsync(coop_abort, getenv("EVC_TEST_COOP_ABORT") ? 1 : 0, sizeof(int), s));
-    int first = 1;
+    // tests only (environment, not part of the ABI): EVC_TEST_COOP_ABORT=k raises the abort flag in front of the
+    // k-th launch of the iteration loop (0: the call starts with it raised), as a timed-out wait would; the call
+    // then takes the caller's retry path after a partially completed solve
+    const char* fake = getenv("EVC_TEST_COOP_ABORT");
+    const int fake_at = fake ? atoi(fake) : -1;
+    if (exchanges) HIP_TRY(hipMemsetAsync(coop_abort, fake_at == 0 ? 1 : 0, sizeof(int), s));
+    int first = 1, launch_no = 0;
     if (o.check_every > 0 && o.stop_rule == EVC_STOP_SKLEARN) {   // error_at_init
         HIP_TRY(fused_iterate(w.fl, fb, w.u, d.N, d.T_, 0, 1, 1, w.err2, o.eps_mode, o.eps, o.l1,
                               c_override, 1, o.loss, exact_div, s));
@@ -230,6 +233,8 @@ int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_sol
         int n = o.iters - done;
         bool check = false;
         if (o.check_every > 0 && n >= o.check_every) { n = o.check_every; check = true; }
+        if (exchanges && fake_at > 0 && launch_no == fake_at) HIP_TRY(hipMemsetAsync(coop_abort, 1, sizeof(int), s));
+        ++launch_no;
         HIP_TRY(fused_iterate(w.fl, fb, w.u, d.N, d.T_, n, first, check ? 1 : 0, w.err2, o.eps_mode,
                               o.eps, o.l1, c_override, o.stop_rule == EVC_STOP_NONE ? 1 : 0, o.loss, exact_div, s));
         first = 0;

@@ -237,8 +237,10 @@ def _solve(A, X, H0, B, *, layout="bin_major", iters=100, eps_mode="add", eps=No
     opts.reserved = ((0 if fused else _lib.FLAG_NO_FUSED) | (_lib.FLAG_EXACT_DIV if exact_div else 0)
                      | (0 if cooperative else _lib.FLAG_NO_EXCHANGE)
                      | (0 if all_resident else _lib.FLAG_NO_ALL_RESIDENT) | ((int(fused_c) & 0xff) << 8))
-    if _fake_coop_timeout:      # tests: the library reads this from the environment, it is not part of the ABI
-        os.environ["EVC_TEST_COOP_ABORT"] = "1"
+    fake = _fake_coop_timeout is not False and _fake_coop_timeout is not None
+    if fake:    # tests: the library reads this from the environment, it is not part of the ABI.  True: the call starts
+        # with the abort flag raised; an int k > 0: it is raised in front of the k-th launch of the iteration loop
+        os.environ["EVC_TEST_COOP_ABORT"] = "0" if _fake_coop_timeout is True else str(int(_fake_coop_timeout))
     if loop_events is not None:     # (torch.cuda.Event, torch.cuda.Event), already created
         opts.ev_loop_start = int(loop_events[0].cuda_event)
         opts.ev_loop_stop = int(loop_events[1].cuda_event)
@@ -262,7 +264,7 @@ def _solve(A, X, H0, B, *, layout="bin_major", iters=100, eps_mode="add", eps=No
                 A_d.data_ptr(), _ld(A_d), X_d.data_ptr(), _ld(X_d), B_d.data_ptr(), _ld(B_d),
                 h_ptr, h_ld, Y_d.data_ptr(), _ld(Y_d), M, Mb, N, T, off_ptr, n_utt, C.byref(opts),
                 ws.data_ptr(), ws.numel(), ni_p, er_p, C.c_void_p(stream))
-    if _fake_coop_timeout:
+    if fake:
         os.environ.pop("EVC_TEST_COOP_ABORT", None)
     _lib.check(st, "evc_nmf_solve" if B is None else "evc_nmf_convert")
     to_np = x_np and out is None

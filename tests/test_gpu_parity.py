@@ -143,6 +143,13 @@ def test_factorize_batched_utterances_match_single_calls():
         assert n == ni
         assert_close64(Hg, act.T, "batched H")
     assert len(set(int(n) for n in n_iter)) > 1, "test should exercise different stop iterations"
+    # hint="latency": the kernels without inter-workgroup exchange (EVC_FLAG_NO_EXCHANGE) - same numbers
+    Hs_lat, n_lat = factorize_utterances(Xs, W, tol=tols, hint="latency")
+    assert list(n_lat) == list(n_iter)
+    for a, b in zip(Hs_lat, Hs_gpu):
+        assert_close64(a, b, "latency hint", rtol=1e-10)
+    with pytest.raises(ValueError, match="hint"):
+        factorize_utterances(Xs, W, tol=tols, hint="fast")
 
 
 # ----------------------------------------------------------------------------------------
@@ -645,16 +652,20 @@ def test_cooperative_timeout_falls_back_to_one_workgroup_per_tile():
                     tol=1e-3, utt_offsets=[0, 50, 90])):
         h0 = kw.pop("H0")
         want, iw = evc.solve_activations(p["A"], p["X"], h0, cooperative=False, info=True, **kw)
-        got, ig = evc.solve_activations(p["A"], p["X"], h0, _fake_coop_timeout=True, info=True, **kw)
-        assert np.array_equal(got, want)
-        assert np.array_equal(ig["n_iter"], iw["n_iter"])
-        assert np.array_equal(np.nan_to_num(ig["err"]), np.nan_to_num(iw["err"]))
+        # True: the flag is up from the start; 2: it goes up in front of the third launch of the iteration loop (the
+        # second configuration runs one launch per 10 iterations), i.e. the redo follows a partly completed solve
+        for when in ((True, 2) if kw.get("check_every") else (True,)):
+            got, ig = evc.solve_activations(p["A"], p["X"], h0, _fake_coop_timeout=when, info=True, **kw)
+            assert np.array_equal(got, want), when
+            assert np.array_equal(ig["n_iter"], iw["n_iter"]), when
+            assert np.array_equal(np.nan_to_num(ig["err"]), np.nan_to_num(iw["err"])), when
 
 
 def test_two_processes_sharing_the_gpu_with_cooperative_launches(tmp_path):
-    """Two processes issuing cooperative launches at the same time can starve each other's workgroups of
-    CUs; every wait is bounded and a timed-out solve is redone non-cooperatively, so both must finish with
-    correct results (whether or not a timeout actually occurs in this run)."""
+    """Two processes on one GPU, each issuing a few solves whose workgroups exchange through device memory: both
+    must finish with correct results (every wait is bounded, and a timed-out solve is redone without exchange -
+    that path itself is tested deterministically by test_cooperative_timeout_falls_back_...).  Three solves each:
+    an integration check of two contexts on the card, not a stress loop."""
     import subprocess
     import sys
     script = tmp_path / "worker.py"
@@ -666,7 +677,7 @@ def test_two_processes_sharing_the_gpu_with_cooperative_launches(tmp_path):
         "p = o.synth_problem(25, 4096, 688, seed=int(sys.argv[1]))\n"
         "want = evc.solve_activations(p['A'], p['X'], iters=20, eps_mode='zero_replace', init='sklearn', cooperative=False)\n"
         "worst = 0.0\n"
-        "for i in range(60):\n"
+        "for i in range(3):\n"
         "    got = evc.solve_activations(p['A'], p['X'], iters=20, eps_mode='zero_replace', init='sklearn')\n"
         "    worst = max(worst, float(np.abs(got - want).max() / np.abs(want).max()))\n"
         "print('WORST', worst)\n"
