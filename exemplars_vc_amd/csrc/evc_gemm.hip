@@ -28,10 +28,24 @@ template <typename T, int BM, int BN, int WM, int WN, bool MU>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_gemm_nt(
     const T* __restrict__ L, int ldl, const T* __restrict__ R, int ldr, T* __restrict__ C, int ldc,
     int Kd, MuEpilogue<T> ep, long slab, int jv) {
-    // split-K: blockIdx.z owns k in [z Kd, (z+1) Kd) and writes its partial product to slab z
-    L += (long)blockIdx.z * Kd;
-    R += (long)blockIdx.z * Kd;
-    C += (long)blockIdx.z * slab;
+    // Block coordinates: the plain product renumbers the grid so that consecutive blocks (x fastest, then y, then the
+    // k-split z) run on ONE XCD (workgroups are dealt to the 8 XCDs round-robin by linear id; see k_gemm2).  With
+    // the 8-way k-split of a one-utterance V = H Am^T an XCD then owns one k-range: it pulls one eighth of the
+    // dictionary and of H through its L2 instead of all of both (C3: 1.07 GB of fabric traffic per iteration).
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (!MU) {
+        const unsigned gx = gridDim.x, gxy = gx * gridDim.y, total = gxy * gridDim.z;
+        const unsigned lin = bx + gx * by + gxy * bz, xcd = lin & 7u;
+        const unsigned v = xcd * (total >> 3) + (xcd < (total & 7u) ? xcd : (total & 7u)) + (lin >> 3);
+        bz = v / gxy;
+        const unsigned rem = v - bz * gxy;
+        by = rem / gx;
+        bx = rem - by * gx;
+    }
+    // split-K: block z owns k in [z Kd, (z+1) Kd) and writes its partial product to slab z
+    L += (long)bz * Kd;
+    R += (long)bz * Kd;
+    C += (long)bz * slab;
     constexpr int NWN = BN / WN;
     constexpr int NTHR = (BM / WM) * NWN * 64;
     constexpr int MI = WM / 16, NI = WN / 16;
@@ -49,7 +63,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_gemm_nt(
     const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w / NWN, wn = w % NWN;
     const int i16 = lane & 15, q = lane >> 4;
-    const long bi = (long)blockIdx.y * BM, bj = (long)blockIdx.x * BN;
+    const long bi = (long)by * BM, bj = (long)bx * BN;
     (void)jv;   // (k_gemm2 skips the zero rows of R from jv on; here the guards cost more than the products)
     constexpr int nni = NI;
 

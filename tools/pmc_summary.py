@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 --pmc csv output per kernel (evc kernels only): mean per dispatch.
-usage: pmc_summary.py <pmc dir> [--json out.json M N K frames dtype kernel_tag]
+usage: pmc_summary.py <pmc dir> [--json out.json M N K frames dtype kernel_tag [steps_per_pass]]
 (the json is what bench.py reads for roofline.traffic: HBM bytes per launch of the dominant kernel, with the
 gfx950 corrections of /opt/skills/guides/MI355X_MICROARCH.md applied: FETCH_SIZE x 2 for wide coalesced reads,
 WRITE_SIZE exact; both counters are reported in KiB)"""
@@ -62,4 +62,33 @@ if "--json" in sys.argv:
         "valu_insts_per_mfma": (c["SQ_INSTS_VALU"] / c["SQ_INSTS_MFMA"]
                                 if c.get("SQ_INSTS_MFMA") else None),
     }
+    if "k_fused" not in name:
+        # generic path: bench.py's timed "launch" is the whole iteration loop (two contractions and, for short
+        # batches, a slab sum per iteration), so the traffic on record is the loop's: every kernel matching the
+        # tag (plus k_sum_slabs), bytes per dispatch x dispatches per bench step
+        steps = int(sys.argv[i + 8]) if len(sys.argv) > i + 8 else 2      # prof_bench.sh: --steps 1 --warmup 1
+        per_kernel, total = {}, 0.0
+        for k in acc:
+            if not (tag in k or "k_sum_slabs" in k) or "FETCH_SIZE" not in acc[k]:
+                continue
+            ck = {n: sum(v) / len(v) for n, v in acc[k].items()}
+            calls = len(acc[k]["FETCH_SIZE"]) / steps
+            if calls < K / 2:                      # (set-up products outside the loop)
+                continue
+            b = 1024.0 * (2 * ck.get("FETCH_SIZE", 0.0) + ck.get("WRITE_SIZE", 0.0))
+            total += b * calls
+            per_kernel[k.replace("evc::", "")] = {
+                "calls_per_step": calls, "hbm_bytes_per_call": b,
+                "mfma_pipe_occupancy": (ck["SQ_VALU_MFMA_BUSY_CYCLES"] / (ck["GRBM_GUI_ACTIVE"] * 128.0)
+                                        if ck.get("SQ_VALU_MFMA_BUSY_CYCLES") and ck.get("GRBM_GUI_ACTIVE") else None),
+                "valu_insts_per_mfma": (ck["SQ_INSTS_VALU"] / ck["SQ_INSTS_MFMA"] if ck.get("SQ_INSTS_MFMA") else None)}
+        doc["kernel"] = tag + " iteration loop: " + " + ".join(sorted(per_kernel))
+        doc["kernels"] = per_kernel
+        doc["hbm_bytes_per_launch"] = total
+        doc["algorithmic_hbm_bytes_per_launch"] = frames * N * w * 4 * K
+        doc["algorithmic_note"] = ("per iteration: V = H Am^T reads H; the update contraction reads H and P and "
+                                   "writes H': 4 x frames x N x element size, x K iterations = one bench launch (loop)")
+        for key in ("FETCH_SIZE_kb", "WRITE_SIZE_kb", "mfma_busy_cycles", "gui_active_cycles_sum_xcd",
+                    "mfma_pipe_occupancy", "valu_insts_per_mfma"):
+            doc.pop(key, None)
     json.dump(doc, open(dest, "w"), indent=1)
