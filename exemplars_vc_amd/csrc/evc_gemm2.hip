@@ -17,6 +17,13 @@
 #include "evc_internal.h"
 #include <type_traits>
 
+// Diagnostic builds only (tools/ubench/gemm2_bench.hip, -DEVC_G2_ABLATE=n): what bounds the kernel is found by
+// taking one part out.  1: the epilogue reads no H / P (update on constants); 2: main loop without global loads
+// (LDS + MFMA pipeline alone); 3: no MFMAs (loads, LDS traffic and barriers alone); 4: no epilogue stores.
+#ifndef EVC_G2_ABLATE
+#define EVC_G2_ABLATE 0
+#endif
+
 namespace evc {
 
 constexpr int EPI_KL = 100, EPI_STORE = 101;      // epilogue bodies besides the four eps modes
@@ -102,18 +109,25 @@ __global__ __launch_bounds__((BF / WF) * (BR / WR) * 64, MINW) void k_gemm2(
     const int r15 = row0 & 15;
     const int pslot = slot ^ (row0 & (SLOTS - 1));
     const int pslotR = sizeof(T) == 8 ? slot ^ key_of(4 * (r15 & 3) + (r15 >> 2)) : pslot;
-    const T* gl = L + (bf0 + row0) * (long)ldl + slot * EPV;
-    const T* gr = R + (br0 + row0) * (long)ldr + slot * EPV;
+    const T* gl = L + (bf0 + row0) * (long)ldl;
+    const T* gr = R + (br0 + row0) * (long)ldr;
     typedef vec StgSet[PL + PR];
     StgSet stg[DEPTH];
     auto fetch = [&](StgSet& st, int k0) {
-        const bool in = k0 + slot * EPV < Kd;             // (Kd is a multiple of 16 elements: a slot is all in or all out)
+        if (EVC_G2_ABLATE == 2) {
 #pragma unroll
-        for (int i = 0; i < PL; ++i)
-            st[i] = in ? *reinterpret_cast<const vec*>(gl + (long)i * RPP * ldl + k0) : vec(0);
+            for (int i = 0; i < PL + PR; ++i) st[i] = vec(T(1e-3));
+            return;
+        }
+        // (Kd is a multiple of 16 elements: a slot is all in or all out.)  A slot beyond Kd re-reads the row's last
+        // one - its products are skipped (nkk in compute) - so that no select stands between a load and its use:
+        // with one, the compiler waits for the previous slab's loads before it issues the next ones
+        int e = k0 + slot * EPV;
+        e = e > Kd - EPV ? Kd - EPV : e;
 #pragma unroll
-        for (int i = 0; i < PR; ++i)
-            st[PL + i] = in ? *reinterpret_cast<const vec*>(gr + (long)i * RPP * ldr + k0) : vec(0);
+        for (int i = 0; i < PL; ++i) st[i] = *reinterpret_cast<const vec*>(gl + (long)i * RPP * ldl + e);
+#pragma unroll
+        for (int i = 0; i < PR; ++i) st[PL + i] = *reinterpret_cast<const vec*>(gr + (long)i * RPP * ldr + e);
     };
     auto stash = [&](const StgSet& st, int buf) {
         T* b = sm + buf * (ROWS * BK);
@@ -156,30 +170,42 @@ __global__ __launch_bounds__((BF / WF) * (BR / WR) * 64, MINW) void k_gemm2(
                 if (PREFP && !ep.kl) pv[PREFP ? ri : 0][PREFP ? fi : 0] = *reinterpret_cast<const vec4*>(ep.P + o);
             }
     };
-    auto compute = [&](int buf, int sl) {
+    // One slab's MFMAs for the first NR 16-row groups of R.  NR is a compile-time count: a run-time bound inside the
+    // unrolled loops puts a branch between every two MFMAs (measured: the skipped products then bought nothing).
+    auto compute_n = [&](int buf, int sl, auto nr_tag) {
+        constexpr int NR = decltype(nr_tag)::value;
         const T* b = sm + buf * (ROWS * BK);
         const int rest = Kd - sl * BK;
         const int nkk = rest >= BK ? KK : rest / (4 * EPV);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             if (kk < nkk) {
-                vec fa[RI], fb[FI];
+                vec fa[NR ? NR : 1], fb[FI];
 #pragma unroll
-                for (int ri = 0; ri < RI; ++ri)
-                    if (ri < nri) fa[ri] = *reinterpret_cast<const vec*>(b + rowA[ri] * BK + ((4 * kk + q) ^ keyA) * EPV);
+                for (int ri = 0; ri < NR; ++ri)
+                    fa[ri] = *reinterpret_cast<const vec*>(b + rowA[ri] * BK + ((4 * kk + q) ^ keyA) * EPV);
 #pragma unroll
                 for (int fi = 0; fi < FI; ++fi)
                     fb[fi] = *reinterpret_cast<const vec*>(b + rowB[fi] * BK + ((4 * kk + q) ^ keyB) * EPV);
 #pragma unroll
                 for (int e = 0; e < EPV; ++e)
 #pragma unroll
-                    for (int ri = 0; ri < RI; ++ri)
-                        if (ri < nri) {
+                    for (int ri = 0; ri < NR; ++ri)
 #pragma unroll
-                            for (int fi = 0; fi < FI; ++fi) acc[ri][fi] = Mma<T>::mma(fa[ri][e], fb[fi][e], acc[ri][fi]);
+                        for (int fi = 0; fi < FI; ++fi) {
+                            if (EVC_G2_ABLATE == 3) acc[ri][fi][e & 3] += fa[ri][e] * fb[fi][e];
+                            else acc[ri][fi] = Mma<T>::mma(fa[ri][e], fb[fi][e], acc[ri][fi]);
                         }
             }
         }
+    };
+    // all groups (every block but the last one along R), or the block that reaches into the padding: 1 .. RI - 1
+    // groups by halving steps (RI is 2 or 4), or none at all
+    auto compute = [&](int buf, int sl) {
+        if (nri == RI) compute_n(buf, sl, std::integral_constant<int, RI>{});
+        else if (RI > 2 && nri == 3) compute_n(buf, sl, std::integral_constant<int, (RI > 2 ? 3 : 1)>{});
+        else if (RI > 2 && nri == 2) compute_n(buf, sl, std::integral_constant<int, (RI > 2 ? 2 : 1)>{});
+        else if (nri >= 1) compute_n(buf, sl, std::integral_constant<int, 1>{});
     };
     if (DEPTH == 1) {
         // two LDS buffers; the next slab's loads fly while this one feeds the MFMAs
@@ -238,13 +264,13 @@ __global__ __launch_bounds__((BF / WF) * (BR / WR) * 64, MINW) void k_gemm2(
 #pragma unroll
                     for (int r = 0; r < 4; ++r) out[r] = acc[ri][fi][r];
                 } else {
-                    const vec4 h = PREF ? hv[PREF ? ri : 0][PREF ? fi : 0]
+                    const vec4 h = EVC_G2_ABLATE == 1 ? vec4(T(0.5)) : PREF ? hv[PREF ? ri : 0][PREF ? fi : 0]
                                         : *reinterpret_cast<const vec4*>(ep.Hin + t * ep.ldh + n0);
                     if (MODE == EPI_KL) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) out[r] = h[r] * acc[ri][fi][r];
                     } else {
-                        const vec4 p = PREFP ? pv[PREFP ? ri : 0][PREFP ? fi : 0]
+                        const vec4 p = EVC_G2_ABLATE == 1 ? vec4(T(0.25)) : PREFP ? pv[PREFP ? ri : 0][PREFP ? fi : 0]
                                              : *reinterpret_cast<const vec4*>(ep.P + t * ep.ldh + n0);
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
@@ -258,7 +284,7 @@ __global__ __launch_bounds__((BF / WF) * (BR / WR) * 64, MINW) void k_gemm2(
 #pragma unroll
                     for (int r = 0; r < 4; ++r) out[r] = live ? out[r] : h[r];
                 }
-                *reinterpret_cast<vec4*>(C + t * ldc + n0) = out;
+                if (EVC_G2_ABLATE != 4 || out[0] == T(-1.2345)) *reinterpret_cast<vec4*>(C + t * ldc + n0) = out;
             }
         }
     };
