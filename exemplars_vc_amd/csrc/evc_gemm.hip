@@ -28,20 +28,9 @@ template <typename T, int BM, int BN, int WM, int WN, bool MU>
 __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_gemm_nt(
     const T* __restrict__ L, int ldl, const T* __restrict__ R, int ldr, T* __restrict__ C, int ldc,
     int Kd, MuEpilogue<T> ep, long slab, int jv) {
-    // Block coordinates: the plain product renumbers the grid so that consecutive blocks (x fastest, then y, then the
-    // k-split z) run on ONE XCD (workgroups are dealt to the 8 XCDs round-robin by linear id; see k_gemm2).  With
-    // the 8-way k-split of a one-utterance V = H Am^T an XCD then owns one k-range: it pulls one eighth of the
-    // dictionary and of H through its L2 instead of all of both (C3: 1.07 GB of fabric traffic per iteration).
-    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (!MU) {
-        const unsigned gx = gridDim.x, gxy = gx * gridDim.y, total = gxy * gridDim.z;
-        const unsigned lin = bx + gx * by + gxy * bz, xcd = lin & 7u;
-        const unsigned v = xcd * (total >> 3) + (xcd < (total & 7u) ? xcd : (total & 7u)) + (lin >> 3);
-        bz = v / gxy;
-        const unsigned rem = v - bz * gxy;
-        by = rem / gx;
-        bx = rem - by * gx;
-    }
+    // (An XCD-aware renumbering of the blocks, as in k_gemm2, was measured here and dropped: no change at C3, where
+    // it cut each XCD's share of the dictionary to one eighth, and 18 % slower on Griffin-Lim's 84-tile products.)
+    const unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     // split-K: block z owns k in [z Kd, (z+1) Kd) and writes its partial product to slab z
     L += (long)bz * Kd;
     R += (long)bz * Kd;
