@@ -15,12 +15,14 @@
 // rows of R are exemplars (or bins), so C[t][n] rows are contiguous in n and a 16-lane
 // group of the MFMA result writes one 128-byte (f64) segment.
 #include "evc_internal.h"
+#include <type_traits>
 
 #include <stdlib.h>
 
 namespace evc {
 
 constexpr int KS = 16;  // k-slab depth staged per barrier
+constexpr int NT_EPI_KL = 100, NT_EPI_STORE = 101;      // epilogue bodies besides the four eps modes
 
 template <typename T, int E> struct VecOf { typedef T type __attribute__((ext_vector_type(E))); };
 
@@ -126,36 +128,57 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_gemm_nt(
         __syncthreads();
     }
 
+    // Epilogue.  The guard mode is a template argument of the body (one uniform switch in front of it instead of one
+    // per element), a stopped frame is a select, the zero padding of the last exemplar block a wave-uniform case -
+    // as in k_gemm2: straight-line code in which the divisions of a tile overlap.
+    auto epilogue_body = [&](auto mode_tag, auto edge_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;          // eps mode; NT_EPI_KL; NT_EPI_STORE
+        constexpr bool edge = decltype(edge_tag)::value;
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long row = bi + wm * WM + 16 * mi + Mma<T>::row(lane, r);
-            bool live = true;
-            if (MU) {
-                const int u = ep.frame_utt[row];
-                live = (u >= 0) && (ep.active[u] != 0);
-            }
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const long col = bj + wn * WN + 16 * ni + i16;
+            for (int r = 0; r < 4; ++r) {
+                const long row = bi + wm * WM + 16 * mi + Mma<T>::row(lane, r);
+                bool live = true;
                 if (MU) {
-                    const T h = ep.Hin[row * ep.ldh + col];
-                    T out = h;
-                    if (live) {
-                        if (ep.kl) {
+                    const int u = ep.frame_utt[row];
+                    live = (u >= 0) && (ep.active[u] != 0);
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const long col = bj + wn * WN + 16 * ni + i16;
+                    if (MODE == NT_EPI_STORE) {
+                        C[row * ldc + col] = acc[mi][ni][r];
+                    } else {
+                        const T h = ep.Hin[row * ep.ldh + col];
+                        T out;
+                        if (MODE == NT_EPI_KL) {
                             out = h * acc[mi][ni][r];
                         } else {
                             const T p = ep.P[row * ep.ldh + col];
-                            out = mu_update<T>(h, p, acc[mi][ni][r], ep.eps_mode, ep.eps, ep.l1);
+                            out = mu_update<T>(h, p, acc[mi][ni][r], MODE, ep.eps, ep.l1);
                         }
-                        if (col >= ep.N) out = T(0);   // keep the zero padding exact (0/0 modes)
+                        if (edge && col >= ep.N) out = T(0);     // keep the zero padding exact (0/0 modes)
+                        C[row * ldc + col] = live ? out : h;
                     }
-                    C[row * ldc + col] = out;
-                } else {
-                    C[row * ldc + col] = acc[mi][ni][r];
                 }
             }
+        }
+    };
+    auto epilogue = [&](auto mode_tag) {
+        if (MU && bj + BN > ep.N) epilogue_body(mode_tag, std::true_type{});
+        else epilogue_body(mode_tag, std::false_type{});
+    };
+    if (!MU) {
+        epilogue(std::integral_constant<int, NT_EPI_STORE>{});
+    } else if (ep.kl) {
+        epilogue(std::integral_constant<int, NT_EPI_KL>{});
+    } else {
+        switch (ep.eps_mode) {
+            case EVC_EPS_ADD: epilogue(std::integral_constant<int, EVC_EPS_ADD>{}); break;
+            case EVC_EPS_ZERO_REPLACE: epilogue(std::integral_constant<int, EVC_EPS_ZERO_REPLACE>{}); break;
+            case EVC_EPS_CLAMP: epilogue(std::integral_constant<int, EVC_EPS_CLAMP>{}); break;
+            default: epilogue(std::integral_constant<int, EVC_EPS_NONE>{}); break;
         }
     }
 }
