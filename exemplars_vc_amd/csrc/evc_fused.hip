@@ -393,9 +393,10 @@ FusedLayout fused_layout(int M, int N, int T_) {
     // rounds of the 8 wavefronts; padding exemplars have zero dictionary columns and zero activations, and
     // 0 * 0 / guard keeps them at zero under every guarded eps mode
     f.NT = N >= 1024 ? round_up(N, 128) / 16 : (N + 15) / 16;
-    // k_fused_all wants whole workgroups of 32 tiles (512 exemplars): pad to that when it costs <= 7 %
+    // k_fused_all wants whole members of 32 tiles (512 exemplars): pad to that when it costs <= 12.5 % (any N from
+    // 4 members on; the padding exemplars cost a proportional share of one member's sweep)
     const int nt32 = round_up(f.NT, 32);
-    if (nt32 * 100L <= f.NT * 107L) f.NT = nt32;
+    if (nt32 * 100L <= f.NT * 112L + f.NT / 2) f.NT = nt32;
     f.TT = (T_ + 15) / 16;
     f.TTp = round_up(f.TT, 4);
     f.a1 = (size_t)f.NT * ((f.msteps + 1) & ~1) * 64;

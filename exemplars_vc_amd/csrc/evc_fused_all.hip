@@ -37,14 +37,15 @@
 // the exchange before).  Every wait is bounded; a member that gives up raises coop_abort, everybody leaves,
 // and the host redoes the solve without inter-workgroup communication (evc_api.hip).
 //
-// More than 8 members (N = 8192 .. 32768, template C == 0, member count at run time): fetching every peer's
-// partial would cost (C - 1) x 3.5 KB per member and exchange, so the exchange becomes a reduce-scatter +
-// all-gather (see the C == 0 branch): two memory round trips, 7 KB fetched per member whatever C is.
+// Other member counts (member count at run time; template C == 0: 16, 32, 64 - whole slices, the lean code of the
+// common sizes; C == -1: 3, 5, 6, 7 and 9 .. 128 - ragged slices): fetching every peer's partial would cost
+// (C - 1) x 3.5 KB per member and exchange, so the exchange becomes a reduce-scatter + all-gather (see the
+// C <= 0 branches): two memory round trips, 7 KB fetched per member whatever C is.
 // Measured at N = 16384 (C5): 5.8 us per step against 5.2 us at N = 4096, where the sweep is the longer half.
 //
-// Requirements (the host checks them, fused_all_members): guarded eps mode, fast quotients, Frobenius
-// loss, NT a multiple of 32, NT / 32 a power of two <= 64.  Frame tiles whose frames are not all live are left to the general kernel
-// (skip_all_live), like in k_fused_res.
+// Requirements (the host checks them, fused_all_members): guarded eps mode, fast quotients, Frobenius loss, NT a
+// multiple of 32 (fused_layout pads N to whole members when that costs <= 12.5 %), at most 128 members.  Frame
+// tiles whose frames are not all live are left to the general kernel (skip_all_live), like in k_fused_res.
 #include "evc_fused_common.h"
 
 namespace evc {
@@ -74,13 +75,13 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
     __shared__ double s_red[2][AW * E];          // partial V' of every wavefront, per half
     __shared__ double s_v[2][E];                 // V, B-operand order
     __shared__ double s_x[2][E];                 // X, B-operand order
-    __shared__ double s_stage[2][C ? 1 : 512];   // reduce-scatter staging (more than 8 members only)
+    __shared__ double s_stage[2][C > 0 ? 1 : 768];   // reduce-scatter staging (more than 8 members only)
     __shared__ unsigned s_hb[2];                 // arrivals of a half's wavefronts at its LDS barrier
     __shared__ int s_fail;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = w8 >> 2, w = w8 & 3, th = tid & (AW * 64 - 1);
-    const int CR = C ? C : a.coop_c;                     // members per group (C == 0: 16, 32 or 64, at run time)
+    const int CR = C > 0 ? C : a.coop_c;                     // members per group (C <= 0: at run time)
     const int member = blockIdx.x % CR;
     const int g = 2 * (blockIdx.x / CR) + half;          // the group this half is a member of
     double* const red = s_red[half];
@@ -130,6 +131,26 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
     const f64x4 dinit = {d0, d0, d0, d0};
     const unsigned lo = fast_lo(mode, eps);
     unsigned seq = 0;                            // exchanges done by this half's group so far
+    // reduce-scatter exchange with ragged slices (C < 0): what this thread publishes and fetches, the same in every exchange
+    int rs_es = 1, rs_len = 0, rs_pub0 = 0, rs_pub1 = 0, rs_src0 = -1, rs_src1 = -1, rs_src2 = -1;
+    if (C < 0) {
+        rs_es = (NE + CR - 1) / CR;                                  // elements per slice
+        rs_len = NE - member * rs_es;                                // of which valid in mine
+        rs_len = rs_len < 0 ? 0 : (rs_len > rs_es ? rs_es : rs_len);
+        const int e0 = th, e1 = th + AW * 64;
+        const int j0 = e0 / rs_es, j1 = (e1 < NE ? e1 : e0) / rs_es;
+        rs_pub0 = (j0 * CR + member) * rs_es + (e0 - j0 * rs_es);
+        rs_pub1 = (j1 * CR + member) * rs_es + ((e1 < NE ? e1 : e0) - j1 * rs_es);
+        // my slice region is [m][ES] row-major at (member * CR) * ES: word idx = m * ES + el, valid while el < len
+        auto src = [&](int idx) {
+            if (idx >= CR * rs_es) return -1;
+            const int el = idx % rs_es;
+            return el < rs_len ? member * CR * rs_es + idx : -1;
+        };
+        rs_src0 = src(th);
+        rs_src1 = src(th + AW * 64);
+        rs_src2 = src(th + 2 * AW * 64);
+    }
     if (tid == 0) s_fail = 0;
     if (tid < 2) s_hb[tid] = 0;
 
@@ -222,8 +243,80 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
                     s0 += red[ww * E + e0];
                     s1 += red[ww * E + (has1 ? e1 : e0)];
                 }
-                if (C == 0) {
-                    // ---- more than 8 members (N > 4096): reduce-scatter + all-gather.  Fetching every member's
+                if (C < 0) {
+                    // ---- any member count without a template of its own (3, 5, 6, 7, 9 ... : N up to 32 x 512 x ...):
+                    // reduce-scatter + all-gather.  Fetching every member's partial costs (C - 1) x 3.5 KB per member
+                    // and exchange (108 KB at C = 32): far longer than the sweep it hides behind.  Instead member m sums
+                    // slice m (ES = ceil(NE / C) elements; the last slices may be short or empty) of all C partials
+                    // and publishes it; everybody then fetches the summed slices: 7 KB per member and exchange
+                    // whatever C is, for a second memory round trip - which the alternation hides.
+                    long long* xb1 = reinterpret_cast<long long*>(a.coop_buf) +
+                                     ((size_t)(seq & 1) * a.groups + g) * (size_t)CR * ALL_RS_STRIDE;
+                    long long* xb2 = reinterpret_cast<long long*>(a.coop_buf) + ALL_SLICE_OFFSET +
+                                     ((size_t)(seq & 1) * a.groups + g) * 512;
+                    const long long tag = (seq >> 1) & 1;
+                    // partials: [slice j][member m][ES], so that what member j reduces is one contiguous run
+                    __hip_atomic_store(xb1 + rs_pub0, (__double_as_longlong(s0) & ~1LL) | tag, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                    if (has1)
+                        __hip_atomic_store(xb1 + rs_pub1, (__double_as_longlong(s1) & ~1LL) | tag, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    bool ok = true;
+                    // poll three words (one memory round trip for all) until each carries the epoch of this exchange
+                    auto fetch3 = [&](const long long* p0, const long long* p1, const long long* p2, long long& b0,
+                                      long long& b1, long long& b2) {
+                        unsigned polls = 0;
+                        for (;;) {
+                            b0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            b1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            b2 = __hip_atomic_load(p2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (__all(!ok || (((b0 ^ tag) | (b1 ^ tag) | (b2 ^ tag)) & 1) == 0)) break;
+                            if (++polls > ALL_POLL_LIMIT ||
+                                ((polls & 63) == 0 &&
+                                 __hip_atomic_load(a.coop_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))
+                                ok = false;
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+                    };
+                    // reduce: my slice of all CR partials (one contiguous run: fully coalesced) goes through LDS; the
+                    // half's 4 wavefronts meet at an LDS counter (a workgroup barrier would stop the other half's
+                    // sweep); then 4 lanes per element sum the members q, q + 4, ... in order and combine (a fixed
+                    // tree: every member obtains the bitwise identical V').  A thread's words are the same in every
+                    // exchange (rs_src*, -1: none - it then re-reads a word it published itself).
+                    {
+                        long long b0, b1, b2;
+                        const long long* own = xb1 + rs_pub0;
+                        fetch3(rs_src0 >= 0 ? xb1 + rs_src0 : own, rs_src1 >= 0 ? xb1 + rs_src1 : own,
+                               rs_src2 >= 0 ? xb1 + rs_src2 : own, b0, b1, b2);
+                        if (rs_src0 >= 0) stage[th] = __longlong_as_double(b0 & ~1LL);
+                        if (rs_src1 >= 0) stage[th + AW * 64] = __longlong_as_double(b1 & ~1LL);
+                        if (rs_src2 >= 0) stage[th + 2 * AW * 64] = __longlong_as_double(b2 & ~1LL);
+                        hb += AW;
+                        if (lane == 0)
+                            __hip_atomic_fetch_add(&s_hb[half], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        while ((int)(__hip_atomic_load(&s_hb[half], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - hb) < 0)
+                            __builtin_amdgcn_s_sleep(1);
+                        const int q = th & 3;
+                        for (int el = th >> 2; el < rs_len; el += AW * 16) {
+                            double v = 0.0;
+                            for (int m = q; m < CR; m += 4) v += stage[m * rs_es + el];
+                            v += __shfl_xor(v, 1, 64);
+                            v += __shfl_xor(v, 2, 64);
+                            if (q == 0)
+                                __hip_atomic_store(xb2 + member * rs_es + el, (__double_as_longlong(v) & ~1LL) | tag,
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                    // gather: the summed slices (element e of V' is word e)
+                    long long g0, g1, g2;
+                    fetch3(xb2 + e0, xb2 + (has1 ? e1 : e0), xb2 + e0, g0, g1, g2);
+                    s0 = __longlong_as_double(g0 & ~1LL);
+                    s1 = __longlong_as_double(g1 & ~1LL);
+                    ++seq;
+                    if (!ok) s_fail = 1;
+                } else if (C == 0) {
+                    // ---- 16, 32 or 64 members (N = 8192, 16384, 32768): the same reduce-scatter with whole slices
+                    // (CR divides NE) and two words per thread: the leaner code of the common sizes.  (original note:) reduce-scatter + all-gather.  Fetching every member's
                     // partial (C - 1 x 3.5 KB per member and exchange: 108 KB at C = 32) would make the exchange far
                     // longer than the sweep it hides behind.  Instead member m sums slice m (NE / C elements) of
                     // all C partials and publishes it; everybody then fetches the C summed slices: 7 KB per member
@@ -320,7 +413,7 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
                     }
                     // every thread fetches its elements of all members; each word carries its own epoch bit, so
                     // a word that lags behind the watched one is simply fetched again
-                    long long b0[C ? C : 1] = {}, b1[C ? C : 1] = {};
+                    long long b0[C > 0 ? C : 1] = {}, b1[C > 0 ? C : 1] = {};
                     polls = 0;
                     while (ok) {
 #pragma unroll
@@ -402,8 +495,9 @@ static hipError_t launch_all(FusedArgs a, int n_cus, hipStream_t s) {
     if (occ < 1) return hipErrorInvalidValue;
     long resident = n_cus;                       // one workgroup (two members) per CU
     if (2 * resident > ALL_MAX_WGS) resident = ALL_MAX_WGS / 2;
-    const int cr = C ? C : a.coop_c;
+    const int cr = C > 0 ? C : a.coop_c;
     if (C == 0 && (cr < 16 || cr > 64 || (cr & (cr - 1)))) return hipErrorInvalidValue;
+    if (C < 0 && (cr < 2 || cr > ALL_MAX_MEMBERS)) return hipErrorInvalidValue;
     int pairs = (int)(resident / cr);            // pairs of groups
     const int want = (a.TT + 1) / 2;
     if (pairs > want) pairs = want;
@@ -411,10 +505,10 @@ static hipError_t launch_all(FusedArgs a, int n_cus, hipStream_t s) {
     a.groups = 2 * pairs;
     if (C != 1) {
         // stale words must not carry the epoch bit of the first two exchanges (0): fill with ones
-        e = hipMemsetAsync(a.coop_buf, 0xFF, sizeof(double) * 2 * (size_t)a.groups * cr * 512, s);
+        e = hipMemsetAsync(a.coop_buf, 0xFF, sizeof(double) * 2 * (size_t)a.groups * cr * (C < 0 ? ALL_RS_STRIDE : 512), s);
         if (e != hipSuccess) return e;
     }
-    if (C == 0) {
+    if (C <= 0) {
         if (2L * a.groups * 512 > ALL_SLICE_ELEMS) return hipErrorInvalidValue;
         e = hipMemsetAsync(a.coop_buf + ALL_SLICE_OFFSET, 0xFF, sizeof(double) * 2 * (size_t)a.groups * 512, s);
         if (e != hipSuccess) return e;
@@ -432,8 +526,8 @@ static hipError_t pick_c(const FusedArgs& a, int n_cus, hipStream_t s) {
         case 8: return launch_all<MSTEPS, 8>(a, n_cus, s);
         case 16:
         case 32:
-        case 64: return launch_all<MSTEPS, 0>(a, n_cus, s);
-        default: return hipErrorInvalidValue;
+        case 64: return launch_all<MSTEPS, 0>(a, n_cus, s);        // run-time members, reduce-scatter, whole slices
+        default: return launch_all<MSTEPS, -1>(a, n_cus, s);      // any other count: ragged slices
     }
 }
 
@@ -442,7 +536,7 @@ int fused_all_members(int NT, int N, int eps_mode, int exact_div, int loss) {
     if (eps_mode == EVC_EPS_NONE || exact_div || loss != EVC_LOSS_FROBENIUS) return 0;
     if (NT % ATILES) return 0;
     const int c = NT / ATILES;
-    return (c >= 1 && c <= 64 && (c & (c - 1)) == 0) ? c : 0;
+    return (c >= 1 && c <= ALL_MAX_MEMBERS) ? c : 0;
 }
 
 hipError_t fused_all_launch(int msteps, const FusedArgs& a, int n_cus, hipStream_t s) {

@@ -163,8 +163,10 @@ struct FusedLayout {
 constexpr int COOP_MAX_TILES = 256;       // frame tiles x cooperating workgroups never exceeds this (one per CU)
 constexpr int ALL_MAX_WGS = 1024;         // resident workgroups of k_fused_all the exchange buffers are sized for
 // k_fused_all with more than 8 members per group: the summed slices live behind the partials in coop_buf
-constexpr long ALL_SLICE_OFFSET = 2L * ALL_MAX_WGS * 512;
-constexpr long ALL_SLICE_ELEMS = 2L * (ALL_MAX_WGS / 16) * 512;   // [2][groups <= ALL_MAX_WGS / 16][512]
+constexpr int ALL_MAX_MEMBERS = 128;      // members per frame tile (N <= 65536)
+constexpr int ALL_RS_STRIDE = 640;        // words per member in a group's partials: C slices x ceil(NE / C) <= NE + C - 1
+constexpr long ALL_SLICE_OFFSET = 2L * ALL_MAX_WGS * ALL_RS_STRIDE;
+constexpr long ALL_SLICE_ELEMS = 2L * (ALL_MAX_WGS / 2) * 512;    // [2][groups <= ALL_MAX_WGS / 2][512]
 int fused_res_coop_factor(int NT, int TT, int n_cus);
 // workgroups per frame tile the all-resident kernel (k_fused_all) uses for this problem; 0: it does not apply
 int fused_all_members(int NT, int N, int eps_mode, int exact_div, int loss);

@@ -110,10 +110,13 @@ def test_c5_full_size(M):
         assert_close64(Hn, H, "C5 without exchange", rtol=1e-10)
 
 
-@pytest.mark.parametrize("M,N", [(25, 8192), (25, 32768), (13, 16384), (32, 8192), (4, 16384)])
+@pytest.mark.parametrize("M,N", [(25, 8192), (25, 32768), (13, 16384), (32, 8192), (4, 16384),
+                                 (25, 1536), (32, 1536), (25, 3000), (25, 5000), (17, 6100), (25, 21000), (32, 40000)])
 def test_reduce_scatter_exchange_member_counts(M, N):
-    """k_fused_all with 16, 32 and 64 members per frame tile (reduce-scatter exchange), bins that fill 1, 4, 7
-    and 8 k-steps: against the oracle, against the kernels without exchange, and twice for bitwise equality
+    """k_fused_all with run-time member counts (reduce-scatter exchange): 16, 32 and 64 members, and the counts that
+    dictionaries of arbitrary size produce after padding to whole members - 3 (N=1536), 6 (3000), 10 (5000), 12
+    (6100), 42 (21000), 79 (40000) - with bins that fill 1, 4, 5, 7 and 8 k-steps (slices of the exchange that are
+    ragged or empty): against the oracle, against the kernels without exchange, and twice for bitwise equality
     (every member must obtain the same V' whatever the arrival order)."""
     import exemplars_vc_amd as evc
     o = oracle()
