@@ -24,6 +24,24 @@
 #define EVC_G2_ABLATE 0
 #endif
 
+// H, P and H' stream through the update kernel once per iteration (541 MB at the STFT flow) beside a dictionary that
+// should stay in the L2: EVC_G2_NT=1 (diagnostic) marks them non-temporal - measured 11 % SLOWER (277 vs 250 us)
+#if defined(EVC_G2_NT) && EVC_G2_NT
+#define EVC_NT_LOAD(p) __builtin_nontemporal_load(p)
+#define EVC_NT_STORE(v, p) __builtin_nontemporal_store(v, p)
+#else
+#define EVC_NT_LOAD(p) (*(p))
+#define EVC_NT_STORE(v, p) (*(p) = (v))
+#endif
+
+#ifdef EVC_G2_STAMP      // diagnostic build (tools/ubench/gemm2_bench.hip): per-wavefront s_memtime stamps of the update kernel
+__device__ long long* evc_g2_dbg = nullptr;
+#define G2_STAMP(i) do { if (MU && evc_g2_dbg && lane == 0) { const unsigned l_ = blockIdx.x + gridDim.x * blockIdx.y; \
+        if (l_ < 2048u) evc_g2_dbg[(l_ * 8 + (tid >> 6)) * 8 + (i)] = (i) == 7 ? (long long)__builtin_amdgcn_s_memrealtime() : (long long)__builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define G2_STAMP(i)
+#endif
+
 namespace evc {
 
 constexpr int EPI_KL = 100, EPI_STORE = 101;      // epilogue bodies besides the four eps modes
@@ -82,6 +100,15 @@ __global__ __launch_bounds__((BF / WF) * (BR / WR) * 64, MINW) void k_gemm2(
     int nri = ((int)(jv - (br0 + wr * WR)) + 15) / 16;
     nri = nri < 0 ? 0 : (nri > RI ? RI : nri);
 
+#ifdef EVC_G2_STAGGER
+    // diagnostic: every second workgroup of the first round starts late, so that the workgroups sharing a CU are
+    // not all in their main loop, then all in their epilogue
+    if (MU) {
+        const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y;
+        if (lin < 1024u && (lin & 1u))
+            for (int i = 0; i < EVC_G2_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     if (MU) {
         // a block whose frames all belong to stopped utterances only carries H over
         int any = 0;
@@ -166,8 +193,8 @@ __global__ __launch_bounds__((BF / WF) * (BR / WR) * 64, MINW) void k_gemm2(
 #pragma unroll
             for (int ri = 0; ri < (PREF ? RI : 0); ++ri) {
                 const long o = (bf0 + wf * WF + 16 * fi + i16) * ep.ldh + br0 + wr * WR + 16 * ri + 4 * q;
-                hv[ri][fi] = *reinterpret_cast<const vec4*>(ep.Hin + o);
-                if (PREFP && !ep.kl) pv[PREFP ? ri : 0][PREFP ? fi : 0] = *reinterpret_cast<const vec4*>(ep.P + o);
+                hv[ri][fi] = EVC_NT_LOAD(reinterpret_cast<const vec4*>(ep.Hin + o));
+                if (PREFP && !ep.kl) pv[PREFP ? ri : 0][PREFP ? fi : 0] = EVC_NT_LOAD(reinterpret_cast<const vec4*>(ep.P + o));
             }
     };
     // One slab's MFMAs for the first NR 16-row groups of R.  NR is a compile-time count: a run-time bound inside the
@@ -207,6 +234,8 @@ __global__ __launch_bounds__((BF / WF) * (BR / WR) * 64, MINW) void k_gemm2(
         else if (RI > 2 && nri == 2) compute_n(buf, sl, std::integral_constant<int, (RI > 2 ? 2 : 1)>{});
         else if (nri >= 1) compute_n(buf, sl, std::integral_constant<int, 1>{});
     };
+    G2_STAMP(0);
+    G2_STAMP(7);
     if (DEPTH == 1) {
         // two LDS buffers; the next slab's loads fly while this one feeds the MFMAs
         fetch(stg[0], 0);
@@ -265,13 +294,13 @@ __global__ __launch_bounds__((BF / WF) * (BR / WR) * 64, MINW) void k_gemm2(
                     for (int r = 0; r < 4; ++r) out[r] = acc[ri][fi][r];
                 } else {
                     const vec4 h = EVC_G2_ABLATE == 1 ? vec4(T(0.5)) : PREF ? hv[PREF ? ri : 0][PREF ? fi : 0]
-                                        : *reinterpret_cast<const vec4*>(ep.Hin + t * ep.ldh + n0);
+                                        : EVC_NT_LOAD(reinterpret_cast<const vec4*>(ep.Hin + t * ep.ldh + n0));
                     if (MODE == EPI_KL) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) out[r] = h[r] * acc[ri][fi][r];
                     } else {
                         const vec4 p = EVC_G2_ABLATE == 1 ? vec4(T(0.25)) : PREFP ? pv[PREFP ? ri : 0][PREFP ? fi : 0]
-                                             : *reinterpret_cast<const vec4*>(ep.P + t * ep.ldh + n0);
+                                             : EVC_NT_LOAD(reinterpret_cast<const vec4*>(ep.P + t * ep.ldh + n0));
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             out[r] = mu_update<T>(h[r], p[r], acc[ri][fi][r], MODE, ep.eps, ep.l1);
@@ -284,13 +313,19 @@ __global__ __launch_bounds__((BF / WF) * (BR / WR) * 64, MINW) void k_gemm2(
 #pragma unroll
                     for (int r = 0; r < 4; ++r) out[r] = live ? out[r] : h[r];
                 }
-                if (EVC_G2_ABLATE != 4 || out[0] == T(-1.2345)) *reinterpret_cast<vec4*>(C + t * ldc + n0) = out;
+                if (EVC_G2_ABLATE != 4 || out[0] == T(-1.2345)) {
+                    if (MU) EVC_NT_STORE(out, reinterpret_cast<vec4*>(C + t * ldc + n0));
+                    else *reinterpret_cast<vec4*>(C + t * ldc + n0) = out;
+                }
             }
         }
     };
     auto epilogue = [&](auto mode_tag) {
+        G2_STAMP(1);
         if (MU && br0 + BR > ep.N) epilogue_body(mode_tag, std::true_type{});
         else epilogue_body(mode_tag, std::false_type{});
+        __builtin_amdgcn_s_waitcnt(0);
+        G2_STAMP(2);
     };
     if (!MU) {
         epilogue(std::integral_constant<int, EPI_STORE>{});
@@ -407,7 +442,12 @@ hipError_t gemm2_mu(const T* L, int ldl, const T* R, int ldr, T* Hout, int I, in
         hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cus <= 0)
         n_cus = 256;
     const long b128 = (long)(I / 128) * (J / 128), b64 = (long)(I / 64) * (J / 128);
+#ifdef EVC_G2_MU_SHAPE
+    const int shape = EVC_G2_MU_SHAPE;       // diagnostic builds: force a block shape
+    (void)b128; (void)b64;
+#else
     const int shape = (sizeof(T) == 4 && I % 128 == 0 && b128 >= 8L * n_cus) ? 1 : (b64 >= 3L * n_cus ? 2 : 3);
+#endif
     return launch_shape<T, true>(shape, L, ldl, R, ldr, Hout, ep.ldh, I, J, Kd, ep, s, 1, 0);
 }
 

@@ -54,6 +54,29 @@ template <typename T> int run(int T_, int N, int M, int reps) {
         for (int r = 0; r < (pass ? reps : 2); ++r) CK(gemm_nt_mu<T>(V, Mj, At, Mk, H1, Tp, Np, Mk, ep, nullptr));
         if (pass) { CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1)); }
     }
+#ifdef EVC_G2_STAMP
+    {
+        long long* d;
+        const size_t n = 2048 * 8 * 8;
+        CK(hipMalloc(&d, sizeof(long long) * n));
+        CK(hipMemset(d, 0, sizeof(long long) * n));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(evc_g2_dbg), &d, sizeof(d)));
+        CK(gemm_nt_mu<T>(V, Mj, At, Mk, H1, Tp, Np, Mk, ep, nullptr));
+        CK(hipDeviceSynchronize());
+        std::vector<long long> st(n);
+        CK(hipMemcpy(st.data(), d, sizeof(long long) * n, hipMemcpyDeviceToHost));
+        long long* z = nullptr;
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(evc_g2_dbg), &z, sizeof(z)));
+        // per workgroup (wave 0): main-loop length and epilogue length
+        double mainl = 0, epi = 0; int cnt = 0;
+        for (int l = 0; l < 2048; ++l) {
+            const long long* q = &st[(l * 8) * 8];
+            if (!q[0]) continue;
+            mainl += q[1] - q[0]; epi += q[2] - q[1]; ++cnt;
+        }
+        printf("  stamps over %d workgroups (wave 0): main loop %.0f ticks, epilogue %.0f ticks\n", cnt, mainl / cnt, epi / cnt);
+    }
+#endif
     printf("  update contraction     : %8.1f us  -> %6.1f Tflop/s\n", ms / reps * 1e3,
            2.0 * T_ * M * (double)N / (ms / reps * 1e-3) / 1e12);
     CK(hipDeviceSynchronize());
