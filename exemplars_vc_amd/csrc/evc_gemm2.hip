@@ -399,12 +399,19 @@ hipError_t gemm2(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int I,
     // 64 x 128 blocks (three per CU) when R has a multiple of 128 rows and the grid fills the CUs; 64 x 64 blocks
     // (four per CU) otherwise: a grid of less than one round runs as long as ONE workgroup does, so the smallest
     // tile is the fastest
+#ifdef EVC_G2_PLAIN_SHAPE      // diagnostic builds: force a block shape of the plain product (0 / 1: 128 x 128)
+    const bool wide = EVC_G2_PLAIN_SHAPE != 3;
+    const int shape = EVC_G2_PLAIN_SHAPE;
+    const long blocks = shape <= 1 ? (long)(I / 128) * (J / 128) : (long)(I / 64) * (J / (wide ? 128 : 64));
+    const long slots = (long)n_cus * (shape == 0 ? 1 : (shape == 1 ? 2 : (wide ? 3 : 4)));
+#else
     const bool wide = J % 128 == 0 && (long)(I / 64) * (J / 128) >= 3L * n_cus;
     const int shape = wide ? 2 : 3;
     const long blocks = (long)(I / 64) * (J / (wide ? 128 : 64));
     // (48 KiB of LDS hold three workgroups per CU for either shape; counting four for the narrow one makes the rule
     // split a little earlier, which measured better: STFT flow, 16 utterances, 157.8 against 155.5 kframes/s)
     const long slots = (long)n_cus * (wide ? 3 : 4);
+#endif
     // split-K so that the grid fills the CUs' workgroup slots in whole rounds: the smallest split whose rounds
     // are >= 85 % full (each workgroup keeps >= 128 of k)
     int splits = 1;
