@@ -496,7 +496,7 @@ static hipError_t launch_all(FusedArgs a, int n_cus, hipStream_t s) {
     long resident = n_cus;                       // one workgroup (two members) per CU
     if (2 * resident > ALL_MAX_WGS) resident = ALL_MAX_WGS / 2;
     const int cr = C > 0 ? C : a.coop_c;
-    if (C == 0 && (cr < 16 || cr > 64 || (cr & (cr - 1)))) return hipErrorInvalidValue;
+    if (C == 0 && (cr < 8 || cr > 64 || (cr & (cr - 1)))) return hipErrorInvalidValue;
     if (C < 0 && (cr < 2 || cr > ALL_MAX_MEMBERS)) return hipErrorInvalidValue;
     int pairs = (int)(resident / cr);            // pairs of groups
     const int want = (a.TT + 1) / 2;
@@ -523,7 +523,10 @@ static hipError_t pick_c(const FusedArgs& a, int n_cus, hipStream_t s) {
         case 1: return launch_all<MSTEPS, 1>(a, n_cus, s);
         case 2: return launch_all<MSTEPS, 2>(a, n_cus, s);
         case 4: return launch_all<MSTEPS, 4>(a, n_cus, s);
-        case 8: return launch_all<MSTEPS, 8>(a, n_cus, s);
+        // 8 members: the direct exchange (every member fetches all 8 partials: 296 GB of fabric traffic per C2 launch)
+        // and the reduce-scatter (37 GB) run equally fast - 953 vs 958 k frames/s at C2, 537 vs 538 k for one
+        // utterance - so the leaner one serves.  (Below 7 members its 4 lanes per element do not cover a slice.)
+        case 8:
         case 16:
         case 32:
         case 64: return launch_all<MSTEPS, 0>(a, n_cus, s);        // run-time members, reduce-scatter, whole slices
