@@ -35,9 +35,10 @@ Dims make_dims(int esize, int M, int N, int T_, int n_utt, int Mb = 0) {
     d.Mj = round_up(M, 64);
     d.Np = round_up(N, 128);
     // frames are padded to the contraction kernels' frame tile: 64 where k_gemm2 is in charge (float32; float64 with
-    // EVC_GEMM2_F64 set), 128 for the first-generation kernel (float64; everything with EVC_GEMM_V1 set)
+    // EVC_GEMM2_F64 set) and for short float64 batches (<= 2048 frames: k_gemm_nt then runs 64-row blocks anyway, and
+    // one 688-frame utterance is 704 rows instead of 768), 128 otherwise (everything with EVC_GEMM_V1 set)
     static const bool v1 = getenv("EVC_GEMM_V1") != nullptr, v2d = getenv("EVC_GEMM2_F64") != nullptr;
-    d.Tp = round_up(T_, (!v1 && (esize == 4 || v2d)) ? 64 : 128);
+    d.Tp = round_up(T_, v1 ? 128 : ((esize == 4 || v2d || T_ <= 2048) ? 64 : 128));
     return d;
 }
 

@@ -55,8 +55,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_gemm_nt(
     const int wm = w / NWN, wn = w % NWN;
     const int i16 = lane & 15, q = lane >> 4;
     const long bi = (long)by * BM, bj = (long)bx * BN;
-    (void)jv;   // (k_gemm2 skips the zero rows of R from jv on; here the guards cost more than the products)
-    constexpr int nni = NI;
+    (void)jv;   // (k_gemm2 skips the zero rows of R from jv on.  Here both forms of the skip - a run-time bound in the
+                // unrolled loops, and a slab body specialised per group count - made the kernel 5-8 % SLOWER at C3.)
 
     if (MU) {
         // a block whose frames all belong to stopped utterances only carries H over
@@ -110,14 +110,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_gemm_nt(
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) a[mi] = sL[buf][kk][wm * WM + 16 * mi + i16];
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                if (ni < nni) b[ni] = sR[buf][kk][wn * WN + 16 * ni + i16];
+            for (int ni = 0; ni < NI; ++ni) b[ni] = sR[buf][kk][wn * WN + 16 * ni + i16];
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni)
-                if (ni < nni) {
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                    for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = Mma<T>::mma(a[mi], b[ni], acc[mi][ni]);
-                }
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = Mma<T>::mma(a[mi], b[ni], acc[mi][ni]);
         }
         if (more) {
 #pragma unroll
@@ -230,12 +227,12 @@ hipError_t gemm_nt(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int 
             cus = 0;
         return gemm2<T>(L, ldl, R, ldr, C, ldc, I, J, Kd, s, scratch, scratch_elems, splits_out, cus, j_valid);
     }
-    if (I % 128 || J % 64 || Kd % KS || Kd <= 0) return hipErrorInvalidValue;
+    if (I % 64 || J % 64 || Kd % KS || Kd <= 0) return hipErrorInvalidValue;
     MuEpilogue<T> ep{};
     // few output tiles (one utterance): 64x64 tiles put 2-4x more workgroups on the 256 CUs, and a long
     // contraction is additionally split over blockIdx.z into slabs of partial products (summed in order)
     const long blocks = (long)(I / 64) * (J / 64);
-    if ((long)(I / 128) * (J / 64) < 256) {
+    if ((long)((I + 127) / 128) * (J / 64) < 256) {
         int splits = 1;
         const long slab = (long)I * ldc;
         if (scratch && ldc == J) {
@@ -258,6 +255,10 @@ hipError_t gemm_nt(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int 
                            slab, C);
         return hipGetLastError();
     }
+    if (I % 128) {      // short batches are padded to 64 frames only: 64-row blocks
+        if (J % 128 == 0) return launch_nt<T, 64, 128, 32, 32, false>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s, 1, 0, j_valid);
+        return launch_nt<T, 64, 64, 32, 32, false>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s, 1, 0, j_valid);
+    }
     if (J % 128 == 0) return launch_nt<T, 128, 128, 64, 32, false>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s, 1, 0, j_valid);
     return launch_nt<T, 128, 64, 32, 32, false>(L, ldl, R, ldr, C, ldc, I, J, Kd, ep, s, 1, 0, j_valid);
 }
@@ -269,13 +270,13 @@ hipError_t gemm_nt_mu(const T* L, int ldl, const T* R, int ldr, T* Hout, int I, 
     if (use_gemm2<T>() && J % 128 == 0 && gemm2_ok<T>(L, ldl, R, ldr, Hout, ep.ldh, I, J, Kd) &&
         gemm2_ok<T>(ep.Hin, ep.ldh, ep.Hin, ep.ldh, ep.kl ? ep.Hin : ep.P, ep.ldh, I, J, Kd))
         return gemm2_mu<T>(L, ldl, R, ldr, Hout, I, J, Kd, ep, s);
-    if (I % 128 || J % 128 || Kd % KS || Kd <= 0) return hipErrorInvalidValue;
+    if (I % 64 || J % 128 || Kd % KS || Kd <= 0) return hipErrorInvalidValue;
     // Tile quantisation for one or two utterances: 128x128 tiles run in rounds of 256 (one per CU), 64x128
     // tiles in rounds of 512 (two per CU, half the work each; a trailing all-padding row tile leaves at
     // once).  C3 (768 x 8192): 384 full tiles = 2 rounds against 768 half tiles = 2 half rounds.
-    const long b128 = (long)(I / 128) * (J / 128), b64 = (long)(I / 64) * (J / 128);
+    const long b128 = (long)((I + 127) / 128) * (J / 128), b64 = (long)(I / 64) * (J / 128);
     const long t128 = 2 * ((b128 + 255) / 256), t64 = (b64 + 511) / 512;     // in half-tile rounds
-    if (I <= 2048 && t64 < t128)
+    if (I % 128 || (I <= 2048 && t64 < t128))
         return launch_nt<T, 64, 128, 32, 32, true>(L, ldl, R, ldr, Hout, ep.ldh, I, J, Kd, ep, s);
     return launch_nt<T, 128, 128, 64, 32, true>(L, ldl, R, ldr, Hout, ep.ldh, I, J, Kd, ep, s);
 }
