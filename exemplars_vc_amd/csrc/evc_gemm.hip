@@ -103,18 +103,28 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_gemm_nt(
             vl = *reinterpret_cast<const vecL*>(gL + (long)(sl + 1) * KS);
             vr = *reinterpret_cast<const vecR*>(gR + (long)(sl + 1) * KS);
         }
+        // fragments of k-step st + 1 are requested before the MFMAs of k-step st issue (two register sets): the
+        // LDS latency then runs beside the matrix pipe instead of in front of every group of MFMAs
+        T fa[2][MI], fb[2][NI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) fa[0][mi] = sL[buf][q][wm * WM + 16 * mi + i16];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) fb[0][ni] = sR[buf][q][wn * WN + 16 * ni + i16];
 #pragma unroll
         for (int st = 0; st < KS / 4; ++st) {
-            const int kk = 4 * st + q;
-            T a[MI], b[NI];
+            if (st + 1 < KS / 4) {
+                const int kk = 4 * (st + 1) + q;
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) a[mi] = sL[buf][kk][wm * WM + 16 * mi + i16];
+                for (int mi = 0; mi < MI; ++mi) fa[(st + 1) & 1][mi] = sL[buf][kk][wm * WM + 16 * mi + i16];
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) b[ni] = sR[buf][kk][wn * WN + 16 * ni + i16];
+                for (int ni = 0; ni < NI; ++ni) fb[(st + 1) & 1][ni] = sR[buf][kk][wn * WN + 16 * ni + i16];
+            }
+            __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise sinks the reads behind the MFMAs)
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = Mma<T>::mma(a[mi], b[ni], acc[mi][ni]);
+                for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = Mma<T>::mma(fa[st & 1][mi], fb[st & 1][ni], acc[mi][ni]);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (more) {
 #pragma unroll
