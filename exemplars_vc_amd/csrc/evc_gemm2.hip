@@ -204,26 +204,39 @@ __global__ __launch_bounds__((BF / WF) * (BR / WR) * 64, MINW) void k_gemm2(
         const T* b = sm + buf * (ROWS * BK);
         const int rest = Kd - sl * BK;
         const int nkk = rest >= BK ? KK : rest / (4 * EPV);
+        // the fragments of group kk + 1 are requested before the MFMAs of group kk issue (two register sets; reads
+        // beyond the k-tail fetch slots whose products are skipped): LDS latency runs beside the matrix pipe
+        constexpr int NS = MINW >= 4 ? 1 : 2;       // (the 128 x 128 two-per-CU shape has no registers for a second set)
+        vec fa[NS][NR ? NR : 1], fb[NS][FI];
+        auto read_group = [&](int kk, vec (&A)[NR ? NR : 1], vec (&B)[FI]) {
+#pragma unroll
+            for (int ri = 0; ri < NR; ++ri)
+                A[ri] = *reinterpret_cast<const vec*>(b + rowA[ri] * BK + ((4 * kk + q) ^ keyA) * EPV);
+#pragma unroll
+            for (int fi = 0; fi < FI; ++fi)
+                B[fi] = *reinterpret_cast<const vec*>(b + rowB[fi] * BK + ((4 * kk + q) ^ keyB) * EPV);
+        };
+        if (NS == 2) read_group(0, fa[0], fb[0]);
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
+            if (NS == 2) {
+                if (kk + 1 < KK) read_group(kk + 1, fa[(kk + 1) & (NS - 1)], fb[(kk + 1) & (NS - 1)]);
+                __builtin_amdgcn_sched_barrier(0);
+            } else if (kk < nkk) {
+                read_group(kk, fa[0], fb[0]);
+            }
             if (kk < nkk) {
-                vec fa[NR ? NR : 1], fb[FI];
-#pragma unroll
-                for (int ri = 0; ri < NR; ++ri)
-                    fa[ri] = *reinterpret_cast<const vec*>(b + rowA[ri] * BK + ((4 * kk + q) ^ keyA) * EPV);
-#pragma unroll
-                for (int fi = 0; fi < FI; ++fi)
-                    fb[fi] = *reinterpret_cast<const vec*>(b + rowB[fi] * BK + ((4 * kk + q) ^ keyB) * EPV);
 #pragma unroll
                 for (int e = 0; e < EPV; ++e)
 #pragma unroll
                     for (int ri = 0; ri < NR; ++ri)
 #pragma unroll
                         for (int fi = 0; fi < FI; ++fi) {
-                            if (EVC_G2_ABLATE == 3) acc[ri][fi][e & 3] += fa[ri][e] * fb[fi][e];
-                            else acc[ri][fi] = Mma<T>::mma(fa[ri][e], fb[fi][e], acc[ri][fi]);
+                            if (EVC_G2_ABLATE == 3) acc[ri][fi][e & 3] += fa[kk & (NS - 1)][ri][e] * fb[kk & (NS - 1)][fi][e];
+                            else acc[ri][fi] = Mma<T>::mma(fa[kk & (NS - 1)][ri][e], fb[kk & (NS - 1)][fi][e], acc[ri][fi]);
                         }
             }
+            if (NS == 2) __builtin_amdgcn_sched_barrier(0);
         }
     };
     // all groups (every block but the last one along R), or the block that reaches into the padding: 1 .. RI - 1
