@@ -96,6 +96,7 @@ Workspace<T> carve(void* base, const Dims& d, int algo, int n_slots, bool fused)
         static_assert(ALL_MAX_WGS >= COOP_MAX_TILES, "coop_buf is sized by k_fused_all's layout");
         w.fb.coop_buf = c.take<double>((size_t)(ALL_SLICE_OFFSET + ALL_SLICE_ELEMS));
         w.fb.coop_cnt = c.take<int>(COOP_MAX_TILES + 1);
+        w.fb.rsum = c.take<double>(32);
         w.fb.coop_c = 1;
     }
     w.flB = FusedLayout{};
@@ -213,6 +214,17 @@ int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_sol
     }
     if (!fb.all_c && !(o.reserved & 4) && c_override == 0 && fused_res_supported(d.N, o.eps_mode, exact_div))
         fb.coop_c = fused_res_coop_factor(w.fl.NT, w.fl.TT, cus);
+    // start values: caller-given ones were imported by the caller of this function; constants are either written
+    // into the packed tiles here, or - first launch on k_fused_all, no residual wanted at init - formed by that kernel
+    fb.init_const = 0;
+    if (o.init_mode != EVC_INIT_GIVEN) {
+        if (fb.all_c >= 1 && o.iters > 0 && !(o.check_every > 0 && o.stop_rule == EVC_STOP_SKLEARN)) {
+            HIP_TRY(fused_rowsum(w.At, d.Mk, d.M, d.N, fb.rsum, s));
+            fb.init_const = 1;
+        } else {
+            HIP_TRY(fused_fill_h(w.fl, fb.Hp, d.N, d.T_, w.u, s));
+        }
+    }
     const bool exchanges = fb.coop_c > 1 || fb.all_c > 1;
     int* coop_abort = fb.coop_cnt + COOP_MAX_TILES;
     // tests only (environment, not part of the ABI): EVC_TEST_COOP_ABORT=k raises the abort flag in front of the
@@ -319,9 +331,7 @@ int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int 
         for (int attempt = 0; attempt < 2; ++attempt) {
             if (o.init_mode == EVC_INIT_GIVEN)
                 HIP_TRY(fused_import_h(w.fl, w.fb.Hp, reinterpret_cast<const double*>(H), ldh, fm ? 1 : 0, T_, N, s));
-            else
-                HIP_TRY(fused_fill_h(w.fl, w.fb.Hp, N, T_, w.u, s));
-            int coop_used = 0, aborted = 0;
+            int coop_used = 0, aborted = 0;       // (constant start values: solve_fused)
             int st = solve_fused(w, d, oo, n_utt, s, &coop_used);
             if (st) return st;
             if (coop_used && check_first) {

@@ -438,6 +438,23 @@ hipError_t fused_export_h(const FusedLayout& f, const double* Hp, double* H, lon
     return hipGetLastError();
 }
 
+// one wavefront per bin: lanes stride the exemplars, then a fixed shuffle tree
+__global__ __launch_bounds__(64) void k_rowsum(const double* __restrict__ At, int ldA, int M, int N,
+                                               double* __restrict__ rsum) {
+    const int m = blockIdx.x, lane = threadIdx.x;
+    double acc = 0.0;
+    if (m < M)
+        for (int n = lane; n < N; n += 64) acc += At[(long)n * ldA + m];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) rsum[m] = acc;
+}
+
+hipError_t fused_rowsum(const double* At, int ldA, int M, int N, double* rsum, hipStream_t s) {
+    hipLaunchKernelGGL(k_rowsum, dim3(32), dim3(64), 0, s, At, ldA, M, N, rsum);
+    return hipGetLastError();
+}
+
 hipError_t fused_fill_h(const FusedLayout& f, double* Hp, int N, int T_, const UttState& u, hipStream_t s) {
     const long tiles = (long)f.TTp * f.NT;
     hipLaunchKernelGGL(k_fill_hp, dim3((unsigned)((tiles * 128 + 255) / 256)), dim3(256), 0, s,
@@ -501,11 +518,15 @@ hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttS
     a.loss = loss; a.exact_div = exact_div;
     a.eps_mode = eps_mode; a.eps = eps; a.l1 = l1;
     a.coop_c = 1; a.coop_buf = nullptr; a.coop_cnt = nullptr; a.coop_abort = nullptr; a.groups = 0;
+    a.init_const = 0; a.h0 = nullptr; a.rsum = nullptr;
     const bool all_res = c_req == 0 && b.all_c >= 1 && b.coop_buf && b.coop_cnt &&
                          fused_all_members(f.NT, N, eps_mode, exact_div, loss) == b.all_c;
     const bool resident = all_res || (c_req == 0 && fused_res_supported(N, eps_mode, exact_div));
     if (!resident) return launch_general(f, a, c_req, s);
-    if (first) {                 // V = A H (and the residual at init) by the general kernel's pre-pass
+    if (first && all_res && b.init_const && iters > 0) {
+        // k_fused_all starts from the utterances' constants itself (every utterance is active at the first launch)
+        a.init_const = 1; a.h0 = u.h0; a.rsum = b.rsum;
+    } else if (first) {          // V = A H (and the residual at init) by the general kernel's pre-pass
         FusedArgs p = a;
         p.iters = 0;
         p.write_err = (iters == 0) ? write_err : 0;
@@ -520,6 +541,7 @@ hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttS
         a.coop_abort = b.coop_cnt + COOP_MAX_TILES;
         e = fused_all_launch(f.msteps, a, b.n_cus, s);
         a.coop_c = 1;            // the general kernel behind it takes no part in any exchange
+        a.first = 0; a.init_const = 0;
     } else {
         if (b.coop_c > 1 && b.coop_buf && b.coop_cnt) {
             a.coop_c = b.coop_c; a.coop_buf = b.coop_buf; a.coop_cnt = b.coop_cnt;
@@ -543,6 +565,7 @@ hipError_t fused_synthesize(const FusedLayout& fB, const double* B2p, const doub
     a.err2 = nullptr; a.frame_utt = u.frame_utt; a.active = u.active;
     a.NT = fB.NT; a.TT = fB.TT; a.N = N; a.T_ = T_;
     a.iters = 0; a.first = 1; a.write_err = 0; a.skip_all_live = 0; a.force_live = 1; a.loss = EVC_LOSS_FROBENIUS; a.exact_div = 0;
+    a.init_const = 0; a.h0 = nullptr; a.rsum = nullptr;
     a.coop_c = 1; a.coop_buf = nullptr; a.coop_cnt = nullptr; a.coop_abort = nullptr; a.groups = 0;
     a.eps_mode = EVC_EPS_ADD; a.eps = 0; a.l1 = 0;
     hipError_t e = dispatch_msteps<1>(fB.msteps, a, s);

@@ -104,12 +104,13 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
         const f64x2* t = reinterpret_cast<const f64x2*>(A1p + (tile0 + sw + AW * k) * (MSP * 64));
 #pragma unroll
         for (int s = 0; s < MSTEPS; s += 2) {
+            // (uniform part of the index on the pointer, the lane last: scalar base + 32-bit lane offset + immediate)
             if (s + 1 < MSTEPS) {
-                const f64x2 v = t[(s >> 1) * 64 + ul];
+                const f64x2 v = (t + (s >> 1) * 64)[ul];
                 a1[s] = v[0];
                 a1[s + 1] = v[1];
             } else {
-                a1[s] = reinterpret_cast<const double*>(&t[(s >> 1) * 64 + ul])[0];
+                a1[s] = reinterpret_cast<const double*>(&(t + (s >> 1) * 64)[ul])[0];
             }
         }
     };
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
         for (int u = 0; u < MT; ++u)
 #pragma unroll
             for (int r = 0; r < 4; r += 2) {
-                const f64x2 v = t[(u * 2 + (r >> 1)) * 64 + ul];
+                const f64x2 v = (t + (u * 2 + (r >> 1)) * 64)[ul];
                 a2[u][r] = v[0];
                 a2[u][r + 1] = v[1];
             }
@@ -171,7 +172,27 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
         HTile h[AKT];
         f64x4 p[AKT];
         double a1[MSTEPS], a2[MT][4];
-        if (valid) {
+        if (valid && a.first && a.init_const) {
+            // first launch from the utterances' constants: H = h0 (0 in the padding), V = A H = h0 rowsum(A)
+            auto h0_of = [&](int fr) {
+                const long t = 16 * tt + fr;
+                const int u = t < a.T_ ? a.frame_utt[t] : -1;
+                return u >= 0 ? a.h0[u] : 0.0;
+            };
+            for (int e = th; e < E; e += AW * 64) {
+                const int s = e >> 6, l = e & 63;
+                const bool in = s < MSTEPS;
+                xL[e] = in ? a.Xp[(tt * MSTEPS + s) * 64 + l] : 0.0;
+                vL[e] = in ? a.rsum[bin_of(s, l >> 4)] * h0_of(l & 15) : 0.0;
+            }
+            const double hv = h0_of(lane & 15);
+#pragma unroll
+            for (int k = 0; k < AKT; ++k) {
+                const long n0 = 16 * (tile0 + AW * k) + 4 * (lane >> 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[k][r] = n0 + r < a.N ? hv : 0.0;
+            }
+        } else if (valid) {
             for (int e = th; e < E; e += AW * 64) {
                 const int s = e >> 6, l = e & 63;
                 const bool in = s < MSTEPS;

@@ -42,6 +42,12 @@ struct FusedArgs {
     int* coop_cnt;           // [TT] arrival counters, zero at launch
     int* coop_abort;         // set when a wait timed out: the launch's results are void
     int groups;              // k_fused_all: groups of coop_c workgroups walking the frame tiles (set by the launcher)
+    // k_fused_all, first launch of a solve with a constant start value per utterance (EVC_INIT_SKLEARN / CONST):
+    // H = h0[utterance] (0 in the padding) and V = A H = h0 * rowsum(A) are formed in the kernel, so neither the
+    // fill of the packed activations nor the V = A H pre-pass runs (2.6 of 184 ms at C2)
+    int init_const;
+    const double* h0;        // [n_utt]
+    const double* rsum;      // [32] row sums of the dictionary (bins), 0 beyond M
 #ifdef EVC_ALL_TIMING
     long long* dbg;          // tools/ubench/fused_all_bench.hip: s_memtime stamps of the first round's steps
 #endif

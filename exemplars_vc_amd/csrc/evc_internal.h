@@ -177,6 +177,8 @@ struct FusedBuffers {
     int* coop_cnt;         // [COOP_MAX_TILES] arrival counters, then one abort flag
     int coop_c;            // cooperating workgroups per frame tile chosen for this call (1 = off)
     int all_c;             // k_fused_all: workgroups per frame tile (0 = that kernel is not used)
+    double* rsum;          // [32] row sums of the dictionary (k_fused_all's in-kernel start)
+    int init_const;        // 1: the first launch forms H = h0 and V = h0 rowsum(A) itself (no fill, no pre-pass)
     int n_cus;             // compute units of the device (sizes k_fused_all's persistent grid)
 };
 bool fused_supported(int M, int N, int T_, int dtype);
@@ -186,6 +188,8 @@ FusedLayout fused_layout(int M, int N, int T_);
 hipError_t fused_pack_dict(const FusedLayout& f, double* A1p, double* A2p, const double* At, int ldA,
                            hipStream_t s);
 hipError_t fused_pack_frames(const FusedLayout& f, double* Xp, const double* Xt, int ldx, hipStream_t s);
+// rsum[m] = sum_n At[n][m] for m < M (fixed order), 0 for M <= m < 32
+hipError_t fused_rowsum(const double* At, int ldA, int M, int N, double* rsum, hipStream_t s);
 // packed activations <-> the caller's H (frame_major: H[t*ldh+n], else H[n*ldh+t]); per-utterance constant fill
 hipError_t fused_import_h(const FusedLayout& f, double* Hp, const double* H, long ldh, int frame_major, int T_,
                           int N, hipStream_t s);
