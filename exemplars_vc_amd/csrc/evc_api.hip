@@ -171,7 +171,7 @@ int synth_rows(const T* Hc, long ldc, const SynthArgs& y, int N, int T_, bool fm
 // single launch when no residual is requested); V is carried between launches.
 template <typename T>
 int solve_fused(const Workspace<T>& w, const Dims& d, const evc_solve_opts& o, int n_utt, hipStream_t s,
-                int* coop_used) {
+                int* coop_used, T* H_out, int ldh, int* exported) {
     return ST_UNSUPPORTED;
 }
 // one host round trip: did a cooperative launch of this call give up waiting for a peer workgroup?
@@ -184,7 +184,8 @@ int coop_timed_out(const Workspace<T>& w, hipStream_t s, int* aborted) {
 }
 template <>
 int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_solve_opts& o, int n_utt,
-                        hipStream_t s, int* coop_used) {
+                        hipStream_t s, int* coop_used, double* H_out, int ldh, int* exported) {
+    *exported = 0;
     const int c_override = (o.reserved >> 8) & 0xff;     // 0 = automatic, 1 / 2 = general kernel
     // pymf's stop rule compares successive errors against 2.2e-16: it only fires at the reference's
     // iteration if the update reaches the same floating-point fixed point, i.e. with correctly rounded
@@ -246,6 +247,11 @@ int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_sol
         int n = o.iters - done;
         bool check = false;
         if (o.check_every > 0 && n >= o.check_every) { n = o.check_every; check = true; }
+        // the last launch of a solve in which nothing can stop writes the caller's H itself (k_fused_all)
+        if (H_out && fb.all_c >= 1 && c_override == 0 && o.stop_rule == EVC_STOP_NONE && done + n == o.iters) {
+            fb.Hx = H_out; fb.ldhx = ldh; fb.hx_frame_major = o.layout == EVC_FRAME_MAJOR ? 1 : 0;
+            *exported = 1;
+        }
         if (exchanges && fake_at > 0 && launch_no == fake_at) HIP_TRY(hipMemsetAsync(coop_abort, 1, sizeof(int), s));
         ++launch_no;
         HIP_TRY(fused_iterate(w.fl, fb, w.u, d.N, d.T_, n, first, check ? 1 : 0, w.err2, o.eps_mode,
@@ -332,14 +338,17 @@ int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int 
             if (o.init_mode == EVC_INIT_GIVEN)
                 HIP_TRY(fused_import_h(w.fl, w.fb.Hp, reinterpret_cast<const double*>(H), ldh, fm ? 1 : 0, T_, N, s));
             int coop_used = 0, aborted = 0;       // (constant start values: solve_fused)
-            int st = solve_fused(w, d, oo, n_utt, s, &coop_used);
+            int exported = 0;
+            // (with caller-given start values the abort flag is read before anything goes to the caller's H: no
+            // direct export then)
+            int st = solve_fused(w, d, oo, n_utt, s, &coop_used, check_first ? (T*)nullptr : H, ldh, &exported);
             if (st) return st;
             if (coop_used && check_first) {
                 st = coop_timed_out(w, s, &aborted);
                 if (st) return st;
             }
             if (!aborted) {
-                st = finish_fused<T>(w, d, o, H, ldh, y, s);
+                st = finish_fused<T>(w, d, o, exported ? (T*)nullptr : H, ldh, y, s);
                 if (st) return st;
                 if (coop_used && !check_first) {
                     st = coop_timed_out(w, s, &aborted);

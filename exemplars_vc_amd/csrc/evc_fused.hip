@@ -518,7 +518,7 @@ hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttS
     a.loss = loss; a.exact_div = exact_div;
     a.eps_mode = eps_mode; a.eps = eps; a.l1 = l1;
     a.coop_c = 1; a.coop_buf = nullptr; a.coop_cnt = nullptr; a.coop_abort = nullptr; a.groups = 0;
-    a.init_const = 0; a.h0 = nullptr; a.rsum = nullptr;
+    a.init_const = 0; a.h0 = nullptr; a.rsum = nullptr; a.Hx = nullptr; a.ldhx = 0; a.hx_frame_major = 0;
     const bool all_res = c_req == 0 && b.all_c >= 1 && b.coop_buf && b.coop_cnt &&
                          fused_all_members(f.NT, N, eps_mode, exact_div, loss) == b.all_c;
     const bool resident = all_res || (c_req == 0 && fused_res_supported(N, eps_mode, exact_div));
@@ -539,9 +539,10 @@ hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttS
     if (all_res) {
         a.coop_c = b.all_c; a.coop_buf = b.coop_buf; a.coop_cnt = b.coop_cnt;
         a.coop_abort = b.coop_cnt + COOP_MAX_TILES;
+        if (all_live_known) { a.Hx = b.Hx; a.ldhx = b.ldhx; a.hx_frame_major = b.hx_frame_major; }
         e = fused_all_launch(f.msteps, a, b.n_cus, s);
         a.coop_c = 1;            // the general kernel behind it takes no part in any exchange
-        a.first = 0; a.init_const = 0;
+        a.first = 0; a.init_const = 0; a.Hx = nullptr;
     } else {
         if (b.coop_c > 1 && b.coop_buf && b.coop_cnt) {
             a.coop_c = b.coop_c; a.coop_buf = b.coop_buf; a.coop_cnt = b.coop_cnt;
@@ -565,6 +566,7 @@ hipError_t fused_synthesize(const FusedLayout& fB, const double* B2p, const doub
     a.err2 = nullptr; a.frame_utt = u.frame_utt; a.active = u.active;
     a.NT = fB.NT; a.TT = fB.TT; a.N = N; a.T_ = T_;
     a.iters = 0; a.first = 1; a.write_err = 0; a.skip_all_live = 0; a.force_live = 1; a.loss = EVC_LOSS_FROBENIUS; a.exact_div = 0;
+    a.Hx = nullptr; a.ldhx = 0; a.hx_frame_major = 0;
     a.init_const = 0; a.h0 = nullptr; a.rsum = nullptr;
     a.coop_c = 1; a.coop_buf = nullptr; a.coop_cnt = nullptr; a.coop_abort = nullptr; a.groups = 0;
     a.eps_mode = EVC_EPS_ADD; a.eps = 0; a.l1 = 0;

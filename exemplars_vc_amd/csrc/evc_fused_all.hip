@@ -487,6 +487,21 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
                 t[ul] = f64x2{h[k][0], h[k][1]};
                 t[ul + 64] = f64x2{h[k][2], h[k][3]};
             }
+            if (a.Hx) {                          // last launch: the caller's H as well (no separate export pass)
+                const long t = 16 * tt + (lane & 15);
+                if (t < a.T_) {
+#pragma unroll
+                    for (int k = 0; k < AKT; ++k) {
+                        const long n0 = 16 * (tile0 + AW * k) + 4 * (lane >> 4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (n0 + r < a.N) {
+                                if (a.hx_frame_major) a.Hx[t * a.ldhx + n0 + r] = h[k][r];
+                                else a.Hx[(n0 + r) * a.ldhx + t] = h[k][r];
+                            }
+                    }
+                }
+            }
             // carry V to the next launch; per-frame squared residual of the final activations
             if (member == 0) {                   // every member holds the same V: one writes it
                 for (int e = th; e < NE; e += AW * 64) a.Vp[(tt * 8 + (e >> 6)) * 64 + (e & 63)] = vL[e];

@@ -48,6 +48,11 @@ struct FusedArgs {
     int init_const;
     const double* h0;        // [n_utt]
     const double* rsum;      // [32] row sums of the dictionary (bins), 0 beyond M
+    // k_fused_all, last launch of a solve in which no utterance can stop: the activations also go straight to the
+    // caller's matrix (the separate export pass reads and writes all of H once more: 2.6 of 180 ms at C2)
+    double* Hx;              // NULL: off
+    long ldhx;
+    int hx_frame_major;      // 1: Hx[t * ldhx + n], 0: Hx[n * ldhx + t]
 #ifdef EVC_ALL_TIMING
     long long* dbg;          // tools/ubench/fused_all_bench.hip: s_memtime stamps of the first round's steps
 #endif

@@ -179,6 +179,9 @@ struct FusedBuffers {
     int all_c;             // k_fused_all: workgroups per frame tile (0 = that kernel is not used)
     double* rsum;          // [32] row sums of the dictionary (k_fused_all's in-kernel start)
     int init_const;        // 1: the first launch forms H = h0 and V = h0 rowsum(A) itself (no fill, no pre-pass)
+    double* Hx;            // k_fused_all's last launch also writes the caller's H (NULL: off); ldhx, hx_frame_major
+    long ldhx;
+    int hx_frame_major;
     int n_cus;             // compute units of the device (sizes k_fused_all's persistent grid)
 };
 bool fused_supported(int M, int N, int T_, int dtype);
