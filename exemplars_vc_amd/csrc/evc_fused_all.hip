@@ -55,6 +55,9 @@ constexpr int AKT = 8;                 // exemplar tiles per wavefront, all regi
 constexpr int ATILES = AW * AKT;       // exemplar tiles per member
 constexpr int ATHREADS = 2 * AW * 64;  // two halves per workgroup
 constexpr unsigned ALL_POLL_LIMIT = 1u << 17;
+#ifndef EVC_ALL_C1_ALTERNATE
+#define EVC_ALL_C1_ALTERNATE 0
+#endif
 
 #ifdef EVC_ALL_TIMING   // diagnostic build only (tools/ubench/fused_all_bench.hip); no stamp executes in the library
 #define EVC_STAMP(i)                                                                                             \
@@ -223,7 +226,9 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
         }
 
         for (int step = 0; step <= 2 * a.iters; ++step) {
-            const bool mine = (step & 1) == half;                 // this half's turn on the matrix pipes
+            // this half's turn on the matrix pipes.  (One member per frame tile - N <= 512 - has no exchange to hide:
+            // both halves then sweep in the same steps, two wavefronts per SIMD.)
+            const bool mine = (C == 1 && !EVC_ALL_C1_ALTERNATE) ? (step & 1) == 0 : (step & 1) == half;
             EVC_STAMP(0);
             if (valid && mine && step < 2 * a.iters) {
                 // ---------------- sweep: h <- h p / (A_j^T V), V' += A_j h over the 8 resident tiles
