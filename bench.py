@@ -8,7 +8,7 @@ Y = B H.  Default workload is BASELINE.json configs[1] ("C2"): M=25 bins, N=4096
 256 utterances x 688 frames (the reference's corpus is 162 utterances; 256 is the next count
 whose frame tiles fill the 256 CUs in whole rounds).
 
-  python bench.py [--gpus N --steps K --warmup W] [--config C1|C2|C3|C5|C5_513|STFT]
+  python bench.py [--gpus N --steps K --warmup W] [--config C1|C2|C3|C4|C5|C5_513|STFT]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 N>1: one process per GPU, utterances sharded (independent shards, no data-path collective;
@@ -39,7 +39,9 @@ PEAK_F64_TFLOPS = 78.6
 PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 
-# BASELINE.json configurations: per-GPU batch = utterances x frames.  C4 is C2 sharded (--gpus N).
+# BASELINE.json configurations: per-GPU batch = utterances x frames.  C4 is C2's sizes on the ragged
+# 162-utterance set; with --gpus N every rank converts the whole set (weak scaling, like the other presets).
+C4_LENGTHS = [704, 216, 513, 494, 945, 640, 497, 1370, 688]     # utterance lengths of the audio bundled with the reference
 PRESETS = {
     "C1": dict(bins=25, exemplars=512, iters=50, utterances=256, frames=688, dtype="f64", l1=0.0,
                label="C1 (BASELINE configs[0]): the reference's CPU-runnable case"),
@@ -47,6 +49,9 @@ PRESETS = {
                label="C2 (BASELINE configs[1])"),
     "C3": dict(bins=513, exemplars=8192, iters=200, utterances=1, frames=688, dtype="f64", l1=0.0,
                label="C3 (BASELINE configs[2]): WORLD-width spectra, one utterance per call"),
+    "C4": dict(bins=25, exemplars=4096, iters=100, utterances=162, frames=688, dtype="f64", l1=0.0, ragged=True,
+               label="C4 (BASELINE configs[3]): the 162-utterance set (lengths of the bundled audio, cycled), one GPU's "
+                     "copy of the whole set"),
     "C5": dict(bins=25, exemplars=16384, iters=100, utterances=16, frames=688, dtype="f64", l1=0.25,
                label="C5 (BASELINE configs[4]): L1-penalised, N=16384"),
     "C5_513": dict(bins=513, exemplars=16384, iters=100, utterances=1, frames=688, dtype="f64", l1=5.13,
@@ -264,7 +269,8 @@ def main():
 
     M, N, K, l1 = cfg["bins"], cfg["exemplars"], cfg["iters"], cfg["l1"]
     U, Tu = cfg["utterances"], cfg["frames"]
-    T = U * Tu
+    lens = [C4_LENGTHS[i % len(C4_LENGTHS)] for i in range(U)] if cfg.get("ragged") else [Tu] * U
+    T = int(sum(lens))
     dtype = cfg["dtype"]
     tdt = torch.float64 if dtype == "f64" else torch.float32
 
@@ -285,7 +291,7 @@ def main():
         X[a0:a1] = Hs @ A + 1e-6
         del Hs
     A, B, X = A.to(tdt), B.to(tdt), X.to(tdt).contiguous()
-    offs = np.arange(U + 1, dtype=np.int32) * Tu
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
     H = torch.empty(T, N, dtype=tdt, device=dev)
     Yout = torch.empty(T, M, dtype=tdt, device=dev)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -339,7 +345,7 @@ def main():
             "dtype": arith, "data": "synthetic",
             "config": {"workload": ("custom: " if custom else cfg["label"] + ": ") +
                                    f"SF1->TF1-shaped dictionary, M={M} bins, N={N} exemplars, K={K} MU iterations"
-                                   f"{f', L1 {l1}' if l1 else ''}, {U} utterance(s) x {Tu} frames = {T} frames per GPU "
+                                   f"{f', L1 {l1}' if l1 else ''}, {U} utterance(s) x {('216..1370 (C4 length set)' if cfg.get('ragged') else Tu)} frames = {T} frames per GPU "
                                    f"per step, solve + synthesis B*H, {dtype} in and out",
                        "preset": args.config if not custom else None,
                        "algo": args.algo, "kernel": kernel,
