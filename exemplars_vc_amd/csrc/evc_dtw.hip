@@ -86,10 +86,24 @@ __global__ __launch_bounds__(DTW_THREADS) void k_dtw_accumulate(DtwArgs g) {
     double* d2 = diag + 2 * W;    // diagonal k-2
     for (int i = tid; i < 3 * W; i += DTW_THREADS) diag[i] = inf;
     __syncthreads();
-    for (int k = 0; k <= Ta + Tb - 2; ++k) {
+    // The local cost of diagonal k + 1 is requested while diagonal k is worked on and the workgroup meets at its
+    // barrier: the chain of Ta + Tb - 1 diagonals then carries LDS and barrier latency only, not a global-memory
+    // round trip each (1.0 us per diagonal before).  One cell per thread and pass; `cn` holds the next pass-0 cost.
+    auto cost_at = [&](int k, int p) {        // local cost of this thread's cell on diagonal k, pass p (0 if none)
         const int ilo = k - (Tb - 1) > 0 ? k - (Tb - 1) : 0;
         const int ihi = k < Ta - 1 ? k : Ta - 1;
-        for (int i = ilo + tid; i <= ihi; i += DTW_THREADS) {
+        const int i = ilo + tid + p * DTW_THREADS;
+        return (k <= Ta + Tb - 2 && i <= ihi) ? Dm[(long)i * Tb + (k - i)] : 0.0;
+    };
+    constexpr int PD = 8;                     // diagonals whose costs are in flight (a request takes ~1 us)
+    double cn[PD];
+#pragma unroll
+    for (int d = 0; d < PD; ++d) cn[d] = cost_at(d, 0);
+    auto diagonal = [&](int k, double c0) {
+        const int ilo = k - (Tb - 1) > 0 ? k - (Tb - 1) : 0;
+        const int ihi = k < Ta - 1 ? k : Ta - 1;
+        int p = 0;
+        for (int i = ilo + tid; i <= ihi; i += DTW_THREADS, ++p) {
             const int j = k - i;
             // slot i+1 of a diagonal holds D[i][.]; slot 0 is the inf border; D0[0][0] = 0 for the first cell
             const double dg = (i == 0 && j == 0) ? 0.0 : ((i > 0 && j > 0) ? d2[i] : inf);
@@ -97,15 +111,31 @@ __global__ __launch_bounds__(DTW_THREADS) void k_dtw_accumulate(DtwArgs g) {
             const double up = i > 0 ? d1[i] : inf;          // D[i-1][j]
             double m = dg < lf ? dg : lf;                   // min(D0[i,j], D0[i+1,j], D0[i,j+1])
             m = m < up ? m : up;
-            const double v = Dm[(long)i * Tb + j] + m;
+            const double v = (p == 0 ? c0 : Dm[(long)i * Tb + j]) + m;      // (further passes: utterances > 1024 frames)
             d0[i + 1] = v;
             Dm[(long)i * Tb + j] = v;
         }
-        __syncthreads();
+        // the diagonals live in LDS: the barrier waits for LDS traffic only.  (__syncthreads() also waits for the
+        // global store above and the cost requests in flight - a memory round trip per diagonal.)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         double* t = d2; d2 = d1; d1 = d0; d0 = t;           // rotate: the oldest diagonal is overwritten next
         // cells of the recycled buffer outside the next diagonal's range must read as "no cell": the
         // range test in dg/lf/up above already guards them, so no clearing is needed
+    };
+    const int last = Ta + Tb - 2;
+    int k0 = 0;
+    for (; k0 + PD - 1 <= last; k0 += PD) {           // whole groups of PD diagonals: ring slots are fixed registers
+#pragma unroll
+        for (int d = 0; d < PD; ++d) {
+            const double c0 = cn[d];
+            cn[d] = cost_at(k0 + d + PD, 0);
+            diagonal(k0 + d, c0);
+        }
     }
+#pragma unroll
+    for (int d = 0; d < PD; ++d)                      // the last, partial group
+        if (k0 + d <= last) diagonal(k0 + d, cn[d]);
+    __syncthreads();      // every store of the accumulated matrix has completed
     // trace-back (dtw package _traceback): one lane walks the path backwards into the end of the buffer
     __shared__ int s_start;
     const int cap = Ta + Tb;
