@@ -328,7 +328,8 @@ def main():
         arith = "f64" if (dtype == "f64" or fused) else "f32"
         peak = PEAK_F64_TFLOPS if arith == "f64" else PEAK_F32_TFLOPS
         if fused:
-            all_res = (not args.no_all_resident) and N % 512 == 0 and N // 512 <= 128 and args.loss == "frobenius"
+            all_res = ((not args.no_all_resident) and N % 512 == 0 and N // 512 <= 128 and
+                       (args.loss == "frobenius" or (args.loss == "kl" and not 2 <= N // 512 < 16)))
             kernel = ("k_fused_all (persistent: H and P register-resident, two members per CU alternating sweep / "
                       "exchange)" if all_res else "k_fused_res (persistent, half of H register-resident, P recomputed)")
             ktag = "k_fused_all" if all_res else "k_fused_res"

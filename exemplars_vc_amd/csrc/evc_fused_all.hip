@@ -43,7 +43,7 @@
 // C <= 0 branches): two memory round trips, 7 KB fetched per member whatever C is.
 // Measured at N = 16384 (C5): 5.8 us per step against 5.2 us at N = 4096, where the sweep is the longer half.
 //
-// Requirements (the host checks them, fused_all_members): guarded eps mode, fast quotients, Frobenius loss, NT a
+// Requirements (the host checks them, fused_all_members): guarded eps mode, fast quotients, Frobenius or KL loss, NT a
 // multiple of 32 (fused_layout pads N to whole members when that costs <= 12.5 %), at most 128 members.  Frame
 // tiles whose frames are not all live are left to the general kernel (skip_all_live), like in k_fused_res.
 #include "evc_fused_common.h"
@@ -69,7 +69,10 @@ constexpr unsigned ALL_POLL_LIMIT = 1u << 17;
 #define EVC_STAMP(i)
 #endif
 
-template <int MSTEPS, int C>
+// KL: the generalised Kullback-Leibler update (sklearn _nmf.py:557-606 with update_H=False): A1p then holds the
+// dictionary divided by its column sums, the sweep's B operand is R = X / max(V, eps) instead of V, the update is
+// h <- h * (A~_j^T R) - no numerator tiles, no division in the sweep - and R is formed where V is combined.
+template <int MSTEPS, int C, bool KL>
 __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
     constexpr int MT = MSTEPS > 4 ? 2 : 1;
     constexpr int E = MT * 4 * 64;               // stride of one V image (accumulator order)
@@ -78,6 +81,7 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
     __shared__ double s_red[2][AW * E];          // partial V' of every wavefront, per half
     __shared__ double s_v[2][E];                 // V, B-operand order
     __shared__ double s_x[2][E];                 // X, B-operand order
+    __shared__ double s_r[2][KL ? E : 1];        // KL: X / max(V, eps), B-operand order
     __shared__ double s_stage[2][C > 0 ? 1 : 768];   // reduce-scatter staging (more than 8 members only)
     __shared__ unsigned s_hb[2];                 // arrivals of a half's wavefronts at its LDS barrier
     __shared__ int s_fail;
@@ -90,6 +94,7 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
     double* const red = s_red[half];
     double* const vL = s_v[half];
     double* const xL = s_x[half];
+    double* const rL = s_r[half];
     double* const stage = s_stage[half];
     unsigned hb = 0;                             // arrivals expected at this half's next LDS barrier
     const double* __restrict__ A1p = a.A1p;
@@ -187,6 +192,7 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
                 const bool in = s < MSTEPS;
                 xL[e] = in ? a.Xp[(tt * MSTEPS + s) * 64 + l] : 0.0;
                 vL[e] = in ? a.rsum[bin_of(s, l >> 4)] * h0_of(l & 15) : 0.0;
+                if (KL) rL[e] = xL[e] / (vL[e] < a.eps ? a.eps : vL[e]);
             }
             const double hv = h0_of(lane & 15);
 #pragma unroll
@@ -201,6 +207,7 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
                 const bool in = s < MSTEPS;
                 xL[e] = in ? a.Xp[(tt * MSTEPS + s) * 64 + l] : 0.0;
                 vL[e] = in ? a.Vp[(tt * 8 + s) * 64 + l] : 0.0;
+                if (KL) rL[e] = xL[e] / (vL[e] < a.eps ? a.eps : vL[e]);       // sklearn _nmf.py:572-576
             }
 #pragma unroll
             for (int k = 0; k < AKT; ++k) {
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
             }
         }
         __syncthreads();
-        if (valid) {                             // numerator tiles, once per frame tile
+        if (valid && !KL) {                      // numerator tiles, once per frame tile
             double x[MSTEPS];
 #pragma unroll
             for (int s = 0; s < MSTEPS; ++s) x[s] = xL[s * 64 + lane];
@@ -225,6 +232,7 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
             }
         }
 
+        if (valid && KL) load_a1(a1, 0);         // (the numerator pass, which otherwise leaves them, is skipped)
         for (int step = 0; step <= 2 * a.iters; ++step) {
             // this half's turn on the matrix pipes.  (One member per frame tile - N <= 512 - has no exchange to hide:
             // both halves then sweep in the same steps, two wavefronts per SIMD.)
@@ -235,7 +243,7 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
                 asm volatile("" : "+s"(sw));
                 double v[MSTEPS];
 #pragma unroll
-                for (int s = 0; s < MSTEPS; ++s) v[s] = vL[s * 64 + lane];
+                for (int s = 0; s < MSTEPS; ++s) v[s] = KL ? rL[s * 64 + lane] : vL[s * 64 + lane];
                 f64x4 vn[MT];
 #pragma unroll
                 for (int u = 0; u < MT; ++u) vn[u] = f64x4{0, 0, 0, 0};
@@ -243,12 +251,17 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
                 for (int k = 0; k < AKT; ++k) {
                     __builtin_amdgcn_sched_barrier(0);
                     load_a2(a2, k);
-                    f64x4 d = dinit;
+                    f64x4 d = KL ? f64x4{0, 0, 0, 0} : dinit;
 #pragma unroll
                     for (int s = 0; s < MSTEPS; ++s) d = Mma<double>::mma(a1[s], v[s], d);
                     load_a1(a1, (k + 1) % AKT);      // the next unit's (or the next sweep's first) fragments
                     __builtin_amdgcn_sched_barrier(0);
-                    mu_tile<false>(h[k], p[k], d, mode, eps, lo);
+                    if (KL) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) h[k][r] *= d[r];
+                    } else {
+                        mu_tile<false>(h[k], p[k], d, mode, eps, lo);
+                    }
 #pragma unroll
                     for (int u = 0; u < MT; ++u)
 #pragma unroll
@@ -475,6 +488,10 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
                 }
                 vL[e0] = s0;
                 if (has1) vL[e1] = s1;
+                if (KL) {
+                    rL[e0] = xL[e0] / (s0 < a.eps ? a.eps : s0);
+                    if (has1) rL[e1] = xL[e1] / (s1 < a.eps ? a.eps : s1);
+                }
             }
             EVC_STAMP(1);
             __syncthreads();
@@ -515,7 +532,7 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
 #pragma unroll
                     for (int s = 0; s < MSTEPS; ++s) {
                         const double x = xL[s * 64 + lane], vv = vL[s * 64 + lane];
-                        e += (x - vv) * (x - vv);
+                        e += KL ? kl_terms(x, vv, a.eps) : (x - vv) * (x - vv);
                     }
                     e += __shfl_xor(e, 16, 64);  // the 4 lane groups hold one frame's bins
                     e += __shfl_xor(e, 32, 64);
@@ -528,10 +545,10 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
     }
 }
 
-template <int MSTEPS, int C>
+template <int MSTEPS, int C, bool KL>
 static hipError_t launch_all(FusedArgs a, int n_cus, hipStream_t s) {
     int occ = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fused_all<MSTEPS, C>, ATHREADS, 0);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_fused_all<MSTEPS, C, KL>, ATHREADS, 0);
     if (e != hipSuccess) return e;
     if (occ < 1) return hipErrorInvalidValue;
     long resident = n_cus;                       // one workgroup (two members) per CU
@@ -554,46 +571,51 @@ static hipError_t launch_all(FusedArgs a, int n_cus, hipStream_t s) {
         e = hipMemsetAsync(a.coop_buf + ALL_SLICE_OFFSET, 0xFF, sizeof(double) * 2 * (size_t)a.groups * 512, s);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_fused_all<MSTEPS, C>), dim3((unsigned)(pairs * cr)), dim3(ATHREADS), 0, s, a);
+    hipLaunchKernelGGL((k_fused_all<MSTEPS, C, KL>), dim3((unsigned)(pairs * cr)), dim3(ATHREADS), 0, s, a);
     return hipGetLastError();
 }
 
-template <int MSTEPS>
+template <int MSTEPS, bool KL>
 static hipError_t pick_c(const FusedArgs& a, int n_cus, hipStream_t s) {
     switch (a.NT / ATILES) {
-        case 1: return launch_all<MSTEPS, 1>(a, n_cus, s);
-        case 2: return launch_all<MSTEPS, 2>(a, n_cus, s);
-        case 4: return launch_all<MSTEPS, 4>(a, n_cus, s);
+        case 1: return launch_all<MSTEPS, 1, KL>(a, n_cus, s);
+        case 2: return launch_all<MSTEPS, 2, KL>(a, n_cus, s);
+        case 4: return launch_all<MSTEPS, 4, KL>(a, n_cus, s);
         // 8 members: the direct exchange (every member fetches all 8 partials: 296 GB of fabric traffic per C2 launch)
         // and the reduce-scatter (37 GB) run equally fast - 953 vs 958 k frames/s at C2, 537 vs 538 k for one
         // utterance - so the leaner one serves.  (Below 7 members its 4 lanes per element do not cover a slice.)
         case 8:
         case 16:
         case 32:
-        case 64: return launch_all<MSTEPS, 0>(a, n_cus, s);        // run-time members, reduce-scatter, whole slices
-        default: return launch_all<MSTEPS, -1>(a, n_cus, s);      // any other count: ragged slices
+        case 64: return launch_all<MSTEPS, 0, KL>(a, n_cus, s);    // run-time members, reduce-scatter, whole slices
+        default: return launch_all<MSTEPS, -1, KL>(a, n_cus, s);  // any other count: ragged slices
     }
 }
 
 // members per frame tile the all-resident kernel would use for this problem, 0 if it does not apply
 int fused_all_members(int NT, int N, int eps_mode, int exact_div, int loss) {
-    if (eps_mode == EVC_EPS_NONE || exact_div || loss != EVC_LOSS_FROBENIUS) return 0;
+    // (either loss: the KL update needs the ZERO_REPLACE guard and no L1, which evc_nmf_solve checks)
+    if (eps_mode == EVC_EPS_NONE || exact_div || (loss != EVC_LOSS_FROBENIUS && loss != EVC_LOSS_KL)) return 0;
     if (NT % ATILES) return 0;
     const int c = NT / ATILES;
+    // The KL sweep has almost no VALU work (3.5 us), so with 2 .. 15 members a step is as long as its exchange and
+    // k_fused_res's streaming form is as fast or faster (C2-sized batches, k frames/s, all-resident vs streamed:
+    // N = 512: 19 800 vs 14 000; 2048: 2 234 vs 2 263; 4096: 930 vs 1 115; 8192: 458 vs 423; 16 384: 214 vs 138)
+    if (loss == EVC_LOSS_KL && c >= 2 && c < 16) return 0;
     return (c >= 1 && c <= ALL_MAX_MEMBERS) ? c : 0;
 }
 
 hipError_t fused_all_launch(int msteps, const FusedArgs& a, int n_cus, hipStream_t s) {
     if (a.NT % ATILES || !a.coop_buf || !a.coop_abort) return hipErrorInvalidValue;
     switch (msteps) {
-        case 1: return pick_c<1>(a, n_cus, s);
-        case 2: return pick_c<2>(a, n_cus, s);
-        case 3: return pick_c<3>(a, n_cus, s);
-        case 4: return pick_c<4>(a, n_cus, s);
-        case 5: return pick_c<5>(a, n_cus, s);
-        case 6: return pick_c<6>(a, n_cus, s);
-        case 7: return pick_c<7>(a, n_cus, s);
-        case 8: return pick_c<8>(a, n_cus, s);
+        case 1: return a.loss == EVC_LOSS_KL ? pick_c<1, true>(a, n_cus, s) : pick_c<1, false>(a, n_cus, s);
+        case 2: return a.loss == EVC_LOSS_KL ? pick_c<2, true>(a, n_cus, s) : pick_c<2, false>(a, n_cus, s);
+        case 3: return a.loss == EVC_LOSS_KL ? pick_c<3, true>(a, n_cus, s) : pick_c<3, false>(a, n_cus, s);
+        case 4: return a.loss == EVC_LOSS_KL ? pick_c<4, true>(a, n_cus, s) : pick_c<4, false>(a, n_cus, s);
+        case 5: return a.loss == EVC_LOSS_KL ? pick_c<5, true>(a, n_cus, s) : pick_c<5, false>(a, n_cus, s);
+        case 6: return a.loss == EVC_LOSS_KL ? pick_c<6, true>(a, n_cus, s) : pick_c<6, false>(a, n_cus, s);
+        case 7: return a.loss == EVC_LOSS_KL ? pick_c<7, true>(a, n_cus, s) : pick_c<7, false>(a, n_cus, s);
+        case 8: return a.loss == EVC_LOSS_KL ? pick_c<8, true>(a, n_cus, s) : pick_c<8, false>(a, n_cus, s);
         default: return hipErrorInvalidValue;
     }
 }

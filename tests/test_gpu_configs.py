@@ -290,3 +290,28 @@ def test_two_host_threads_on_two_streams():
     for i in range(2):
         for r in range(6):
             assert np.array_equal(res[i][r].cpu().numpy(), solo[i]), (i, r)
+
+
+@pytest.mark.parametrize("M,N", [(25, 512), (7, 400), (25, 8192), (32, 16384), (13, 21000)])
+def test_kl_update_on_the_all_resident_kernel(M, N):
+    """The generalised-KL update (sklearn beta_loss='kullback-leibler', update_H=False) on k_fused_all: one member
+    (no exchange) and 16, 32 and 42 members (reduce-scatter), start values formed in the kernel, an all-zero frame
+    (numerator 0), with and without the error trace - against the oracle's restatement of scikit-learn and
+    against the streamed kernel."""
+    import exemplars_vc_amd as evc
+    o = oracle()
+    K, T = 25, 90
+    p = o.synth_problem(M, N, T, seed=7 * N + M)
+    X = np.ascontiguousarray(p["X"].T)
+    X[5] = 0.0
+    W = np.ascontiguousarray(p["A"].T)
+    want, n_iter, _ = o.sklearn_mu_fixed_dictionary_kl(X, W, K, 0.0)
+    kw = dict(layout="frame_major", iters=K, eps_mode="zero_replace", init="sklearn", loss="kl")
+    got = evc.solve_activations(W, X, **kw)
+    assert_close64(got, want, f"KL all-resident M={M} N={N}")
+    res = evc.solve_activations(W, X, all_resident=False, **kw)
+    assert_close64(got, res, "against the streamed kernel", rtol=1e-10)
+    got2, info = evc.solve_activations(W, X, check_every=5, info=True, **kw)
+    res2, info_r = evc.solve_activations(W, X, check_every=5, info=True, all_resident=False, **kw)
+    assert_close64(got2, want, "KL with error trace")
+    np.testing.assert_allclose(info["err"], info_r["err"], rtol=1e-9, equal_nan=True)

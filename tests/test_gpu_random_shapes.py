@@ -43,6 +43,8 @@ def test_default_selection_equals_the_restricted_path(seed):
         kw["init_value"] = 0.37
     if seed % 4 == 3:
         kw.update(check_every=5, info=True)              # several launches, error trace
+    if seed % 5 == 2:                                    # the KL update (scikit-learn's guard only, no L1)
+        kw.update(loss="kl", eps_mode="zero_replace")
     got = evc.convert(tr(p["A"]), tr(p["X"]), tr(p["B"]), **kw)
     want = evc.convert(tr(p["A"]), tr(p["X"]), tr(p["B"]), all_resident=False, cooperative=False, **kw)
     for g, w, name in zip(got[:2], want[:2], ("H", "Y")):
