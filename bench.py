@@ -11,8 +11,12 @@ whose frame tiles fill the 256 CUs in whole rounds).
   python bench.py [--gpus N --steps K --warmup W] [--config C1|C2|C3|C4|C5|C5_513|STFT]
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N>1: one process per GPU, utterances sharded (independent shards, no data-path collective;
-torch.distributed is used for the barrier and the max-over-ranks only).  Prints ONE JSON line on rank 0.
+N>1: one process per GPU (independent shards, no data-path collective; torch.distributed is used for the barrier,
+the max-over-ranks and the ranks_seen count only).  `python bench.py --gpus N` without a launcher starts the N
+ranks itself: the parent, before it has touched the GPU, runs `python -m torch.distributed.run --nproc-per-node N
+bench.py ...` as a child process, relays its output and exits with its status.  Every preset but C4 gives each rank
+its own copy of the batch (weak scaling); C4 is ONE 162-utterance set split over the ranks by
+shard.partition_utterances (strong scaling, BASELINE configs[3]).  Prints ONE JSON line on rank 0.
 
 Besides the contract's fields the line carries
   roofline       algorithmic flops of the executed algebra / HIP-event time of the iteration loop (recorded by the
@@ -40,7 +44,7 @@ PEAK_F32_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
 
 # BASELINE.json configurations: per-GPU batch = utterances x frames.  C4 is C2's sizes on the ragged
-# 162-utterance set; with --gpus N every rank converts the whole set (weak scaling, like the other presets).
+# 162-utterance set, which with --gpus N is split over the ranks (LPT shards, strong scaling).
 C4_LENGTHS = [704, 216, 513, 494, 945, 640, 497, 1370, 688]     # utterance lengths of the audio bundled with the reference
 PRESETS = {
     "C1": dict(bins=25, exemplars=512, iters=50, utterances=256, frames=688, dtype="f64", l1=0.0,
@@ -50,8 +54,8 @@ PRESETS = {
     "C3": dict(bins=513, exemplars=8192, iters=200, utterances=1, frames=688, dtype="f64", l1=0.0,
                label="C3 (BASELINE configs[2]): WORLD-width spectra, one utterance per call"),
     "C4": dict(bins=25, exemplars=4096, iters=100, utterances=162, frames=688, dtype="f64", l1=0.0, ragged=True,
-               label="C4 (BASELINE configs[3]): the 162-utterance set (lengths of the bundled audio, cycled), one GPU's "
-                     "copy of the whole set"),
+               label="C4 (BASELINE configs[3]): the 162-utterance set (lengths of the bundled audio, cycled), "
+                     "utterance-sharded over the ranks"),
     "C5": dict(bins=25, exemplars=16384, iters=100, utterances=16, frames=688, dtype="f64", l1=0.25,
                label="C5 (BASELINE configs[4]): L1-penalised, N=16384"),
     "C5_513": dict(bins=513, exemplars=16384, iters=100, utterances=1, frames=688, dtype="f64", l1=5.13,
@@ -112,9 +116,45 @@ def max_over_ranks(elapsed, dist=None, device=None):
     return float(t.item())
 
 
-def job_throughput(world, units_per_rank, steps, elapsed):
-    """whole-job aggregate: every rank processed `units_per_rank` units per step (weak scaling)"""
-    return world * units_per_rank * steps / elapsed
+def job_throughput(world, units_per_rank, steps, elapsed, total_units=None):
+    """whole-job aggregate: every rank processed `units_per_rank` units per step (weak scaling), or - total_units
+    given - the ranks together processed that many per step (strong scaling: one set sharded over the ranks)"""
+    per_step = world * units_per_rank if total_units is None else total_units
+    return per_step * steps / elapsed
+
+
+def shard_of_rank(lengths, world, rank):
+    """utterance indices of this rank's LPT shard of one set (exemplars_vc_amd.shard.partition_utterances)"""
+    from exemplars_vc_amd.shard import partition_utterances
+    return partition_utterances(lengths, world)[rank]
+
+
+def launcher_command(argv, gpus, port, python=None):
+    """the child command `python bench.py --gpus N` runs when no launcher started it: one rank per GPU"""
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py")] + list(argv)
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(argv, gpus, run=None):
+    """Parent side of `python bench.py --gpus N` (N > 1, no launcher in the environment): start the N ranks as a
+    CHILD process - never exec, and before this process has made any GPU call - relay what they print and
+    return the child's exit status."""
+    import subprocess
+    cmd = launcher_command(argv, gpus, free_port())
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    p = (run or subprocess.run)(cmd, env=env)
+    return int(p.returncode)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -246,6 +286,11 @@ def main():
     ap.add_argument("--same-device", action="store_true",
                     help="testing only: every rank uses cuda:0 (rehearse the N>1 path on a 1-GPU box)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start the ranks ourselves (torch is not imported yet - this process never touches the GPU)
+        sys.exit(spawn_ranks(sys.argv[1:], args.gpus))
     cfg = dict(PRESETS[args.config])
     for k in ("bins", "exemplars", "iters", "utterances", "frames", "l1", "dtype"):
         if getattr(args, k) is not None:
@@ -256,6 +301,8 @@ def main():
     import exemplars_vc_amd as evc
 
     world, rank, local_rank = dist_env(args.same_device)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -270,6 +317,13 @@ def main():
     M, N, K, l1 = cfg["bins"], cfg["exemplars"], cfg["iters"], cfg["l1"]
     U, Tu = cfg["utterances"], cfg["frames"]
     lens = [C4_LENGTHS[i % len(C4_LENGTHS)] for i in range(U)] if cfg.get("ragged") else [Tu] * U
+    # C4 is ONE set: each rank converts its LPT shard of it (strong scaling); the other presets give every rank a
+    # batch of its own (weak scaling)
+    sharded = bool(cfg.get("ragged")) and not custom
+    T_set = int(sum(lens))
+    if sharded and world > 1:
+        lens = [lens[i] for i in shard_of_rank(lens, world, rank)]
+        U = len(lens)
     T = int(sum(lens))
     dtype = cfg["dtype"]
     tdt = torch.float64 if dtype == "f64" else torch.float32
@@ -298,16 +352,20 @@ def main():
     ev0.record(); ev1.record()          # force creation of the underlying hipEvent_t
     torch.cuda.synchronize()
     loop_ms = []
+    sinfo = {}
+    counts = {"redo": 0}
     solve_kw = dict(layout="frame_major", iters=K, eps_mode="zero_replace", init="sklearn", algo=args.algo, l1=l1,
                     fused=not args.no_fused, fused_c=args.fused_c, loss=args.loss,
                     all_resident=not args.no_all_resident)
 
     def step(timed):
         # factorize() + convert(): H (T x N) and Y = H B (T x Mb) both delivered in HBM
-        _, Y = evc.convert(A, X, B, utt_offsets=offs, out=H, out_y=Yout, loop_events=(ev0, ev1), **solve_kw)
+        _, Y = evc.convert(A, X, B, utt_offsets=offs, out=H, out_y=Yout, loop_events=(ev0, ev1), solve_info=sinfo,
+                           **solve_kw)
         if timed:
             ev1.synchronize()
             loop_ms.append(ev0.elapsed_time(ev1))
+            counts["redo"] += sinfo.get("redo", 0)
         return Y
 
     def barrier():
@@ -315,42 +373,61 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    elapsed = run_timed(step, args.steps, args.warmup, barrier)
-    elapsed = max_over_ranks(elapsed, dist, dev if (dist is not None and args.dist_backend == "nccl") else None)
+    elapsed_own = run_timed(step, args.steps, args.warmup, barrier)
+    cdev = dev if (dist is not None and args.dist_backend == "nccl") else None
+    elapsed = max_over_ranks(elapsed_own, dist, cdev)
+    ranks_seen, per_rank = 1, [T * args.steps / elapsed_own]
+    if dist is not None:
+        one = torch.ones(1, dtype=torch.float64, device=cdev if cdev is not None else "cpu")
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)          # every rank of the group adds itself
+        ranks_seen = int(round(float(one.item())))
+        mine = torch.tensor([T * args.steps / elapsed_own], dtype=torch.float64, device=cdev if cdev is not None else "cpu")
+        rates = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(rates, mine)
+        per_rank = [float(r.item()) for r in rates]
 
     if rank == 0:
-        value = job_throughput(world, T, args.steps, elapsed)
+        value = job_throughput(world, T, args.steps, elapsed, T_set if sharded else None)
         loop_s = float(np.mean(loop_ms)) / 1e3
         fl_loop = loop_flops_per_frame(M, N, K, args.algo) * T
         achieved = fl_loop / loop_s / 1e12
-        fused = args.algo == "factored" and M <= 32 and not args.no_fused
+        # the kernel the library reports it ran (evc_solve_info), not a guess from the shape
+        ktag = sinfo.get("kernel", "unknown")
+        fused64 = ktag in ("k_fused_all", "k_fused_res", "k_fused_mu")
         # float32 callers with M <= 32 are widened onto the float64 fused kernels: the arithmetic type is f64
-        arith = "f64" if (dtype == "f64" or fused) else "f32"
+        arith = "f64" if (dtype == "f64" or fused64) else "f32"
         peak = PEAK_F64_TFLOPS if arith == "f64" else PEAK_F32_TFLOPS
-        if fused:
-            all_res = ((not args.no_all_resident) and N % 512 == 0 and N // 512 <= 128 and
-                       (args.loss == "frobenius" or (args.loss == "kl" and not 2 <= N // 512 < 16)))
-            kernel = ("k_fused_all (persistent: H and P register-resident, two members per CU alternating sweep / "
-                      "exchange)" if all_res else "k_fused_res (persistent, half of H register-resident, P recomputed)")
-            ktag = "k_fused_all" if all_res else "k_fused_res"
-        else:
-            kernel = ("k_gemm2" if arith == "f32" else "k_gemm_nt") + " x2 per iteration (V = H Am^T, then the update as epilogue of V At^T)"
-            ktag = "k_gemm2" if arith == "f32" else "k_gemm_nt"
+        kernel = {
+            "k_fused_all": "k_fused_all (persistent: H and P register-resident, two members per CU alternating sweep / exchange)",
+            "k_fused_res": "k_fused_res (persistent, half of H register-resident, P recomputed)",
+            "k_fused_mu": "k_fused_mu (persistent fused update, activations streamed)",
+            "k_fused_wide": "k_fused_wide (fused FACTORED for M > 32: task queue over frame groups x exemplar ranges, "
+                            "dictionary blocks shared through LDS, V resident per wavefront, H and P streamed once)",
+            "k_gemm2": "k_gemm2 x2 per iteration (V = H Am^T, then the update as epilogue of V At^T)",
+            "k_gemm_nt": "k_gemm_nt x2 per iteration (V = H Am^T, then the update as epilogue of V At^T)",
+        }.get(ktag, ktag) + f"; members per frame tile/group: {sinfo.get('members', 1)}"
         traffic, traffic_src = pmc_traffic(ktag, M, N, K, T, dtype)
         res = {
             "metric": "spectral frames/sec converted (100 NMF iters, N=4096 dict)" if (N, K) == (4096, 100)
                       else f"spectral frames/sec converted ({K} NMF iters, N={N} dict)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": arith, "data": "synthetic",
             "config": {"workload": ("custom: " if custom else cfg["label"] + ": ") +
                                    f"SF1->TF1-shaped dictionary, M={M} bins, N={N} exemplars, K={K} MU iterations"
-                                   f"{f', L1 {l1}' if l1 else ''}, {U} utterance(s) x {('216..1370 (C4 length set)' if cfg.get('ragged') else Tu)} frames = {T} frames per GPU "
+                                   f"{f', L1 {l1}' if l1 else ''}, {U} utterance(s) x {('216..1370 (C4 length set)' if cfg.get('ragged') else Tu)} frames = {T} frames "
+                                   f"{'on rank 0 (its shard of ' + str(T_set) + ')' if sharded and world > 1 else 'per GPU'} "
                                    f"per step, solve + synthesis B*H, {dtype} in and out",
                        "preset": args.config if not custom else None,
                        "algo": args.algo, "kernel": kernel,
-                       "frames_per_gpu": T, "parallelism": f"utterance shards x{world}", "io_dtype": dtype},
+                       "frames_per_gpu": T, "frames_per_step_all_gpus": T_set if sharded else world * T,
+                       "parallelism": (f"one {cfg['utterances']}-utterance set in {world} LPT shard(s)" if sharded
+                                       else f"utterance shards x{world}"),
+                       "members": sinfo.get("members", 1), "launches_per_step": sinfo.get("launches"),
+                       "io_dtype": dtype},
+            "ranks_seen": ranks_seen, "frames_per_s_per_rank": per_rank,
+            "visible_devices": torch.cuda.device_count(), "redo_count": counts["redo"],
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,

@@ -35,10 +35,22 @@ class SolveOpts(C.Structure):
         ("struct_bytes", C.c_int), ("dtype", C.c_int), ("layout", C.c_int), ("algo", C.c_int),
         ("iters", C.c_int), ("eps_mode", C.c_int), ("init_mode", C.c_int),
         ("check_every", C.c_int), ("stop_rule", C.c_int), ("reserved", C.c_int),
-        ("loss", C.c_int), ("reserved2", C.c_int),
+        ("loss", C.c_int), ("test_abort_at", C.c_int),
         ("eps", C.c_double), ("l1", C.c_double), ("tol", C.c_double), ("init_value", C.c_double),
-        ("ev_loop_start", C.c_void_p), ("ev_loop_stop", C.c_void_p),
+        ("ev_loop_start", C.c_void_p), ("ev_loop_stop", C.c_void_p), ("info", C.c_void_p),
     ]
+
+
+class SolveInfo(C.Structure):
+    """Mirror of `evc_solve_info` (include/evc.h): what the library actually ran."""
+    _fields_ = [
+        ("struct_bytes", C.c_int), ("kernel", C.c_int), ("members", C.c_int), ("launches", C.c_int),
+        ("redo", C.c_int), ("exchange", C.c_int), ("prepared", C.c_int), ("reserved", C.c_int),
+    ]
+
+
+KERNEL_NAMES = {0: "none", 1: "k_gemm_nt", 2: "k_gemm2", 3: "k_fused_mu", 4: "k_fused_res", 5: "k_fused_all",
+                6: "k_fused_wide"}
 
 
 class EvcError(RuntimeError):

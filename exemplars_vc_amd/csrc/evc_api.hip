@@ -34,11 +34,16 @@ Dims make_dims(int esize, int M, int N, int T_, int n_utt, int Mb = 0) {
     d.Mk = round_up(M, 16);
     d.Mj = round_up(M, 64);
     d.Np = round_up(N, 128);
-    // frames are padded to the contraction kernels' frame tile: 64 where k_gemm2 is in charge (float32; float64 with
-    // EVC_GEMM2_F64 set) and for short float64 batches (<= 2048 frames: k_gemm_nt then runs 64-row blocks anyway, and
-    // one 688-frame utterance is 704 rows instead of 768), 128 otherwise (everything with EVC_GEMM_V1 set)
-    static const bool v1 = getenv("EVC_GEMM_V1") != nullptr, v2d = getenv("EVC_GEMM2_F64") != nullptr;
-    d.Tp = round_up(T_, v1 ? 128 : ((esize == 4 || v2d || T_ <= 2048) ? 64 : 128));
+    // frames are padded to the contraction kernels' frame tile: 64 where k_gemm2 is in charge (float32) and for short
+    // float64 batches (<= 2048 frames: k_gemm_nt then runs 64-row blocks anyway, and one 688-frame utterance is 704
+    // rows instead of 768), 128 otherwise (diagnostic builds: see use_gemm2 in evc_gemm.hip)
+#if defined(EVC_DIAG_GEMM_V1)
+    d.Tp = round_up(T_, 128);
+#elif defined(EVC_DIAG_GEMM2_F64)
+    d.Tp = round_up(T_, 64);
+#else
+    d.Tp = round_up(T_, (esize == 4 || T_ <= 2048) ? 64 : 128);
+#endif
     return d;
 }
 
@@ -171,7 +176,7 @@ int synth_rows(const T* Hc, long ldc, const SynthArgs& y, int N, int T_, bool fm
 // single launch when no residual is requested); V is carried between launches.
 template <typename T>
 int solve_fused(const Workspace<T>& w, const Dims& d, const evc_solve_opts& o, int n_utt, hipStream_t s,
-                int* coop_used, T* H_out, int ldh, int* exported) {
+                int* coop_used, T* H_out, int ldh, int* exported, evc_solve_info* inf) {
     return ST_UNSUPPORTED;
 }
 // one host round trip: did a cooperative launch of this call give up waiting for a peer workgroup?
@@ -184,7 +189,7 @@ int coop_timed_out(const Workspace<T>& w, hipStream_t s, int* aborted) {
 }
 template <>
 int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_solve_opts& o, int n_utt,
-                        hipStream_t s, int* coop_used, double* H_out, int ldh, int* exported) {
+                        hipStream_t s, int* coop_used, double* H_out, int ldh, int* exported, evc_solve_info* inf) {
     *exported = 0;
     const int c_override = (o.reserved >> 8) & 0xff;     // 0 = automatic, 1 / 2 = general kernel
     // pymf's stop rule compares successive errors against 2.2e-16: it only fires at the reference's
@@ -192,10 +197,10 @@ int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_sol
     // quotients (reserved bit 1 asks for them explicitly)
     const int exact_div = (o.stop_rule == EVC_STOP_PYMF || (o.reserved & 2)) ? 1 : 0;
     if (o.loss == EVC_LOSS_KL) {     // D/P operand order from the scaled dictionary, V' operand order from A
-        HIP_TRY(fused_pack_dict(w.fl, w.fb.A1p, nullptr, w.Akl, d.Mk, s));
-        HIP_TRY(fused_pack_dict(w.fl, nullptr, w.fb.A2p, w.At, d.Mk, s));
+        HIP_TRY(fused_pack_dict(w.fl, w.fb.A1p, nullptr, w.Akl, d.Mk, d.Np, s));
+        HIP_TRY(fused_pack_dict(w.fl, nullptr, w.fb.A2p, w.At, d.Mk, d.Np, s));
     } else {
-        HIP_TRY(fused_pack_dict(w.fl, w.fb.A1p, w.fb.A2p, w.At, d.Mk, s));
+        HIP_TRY(fused_pack_dict(w.fl, w.fb.A1p, w.fb.A2p, w.At, d.Mk, d.Np, s));
     }
     HIP_TRY(fused_pack_frames(w.fl, w.fb.Xp, w.Xt, d.Mk, s));
     // few frame tiles (one or two utterances): several workgroups share a tile and split the exemplars
@@ -227,12 +232,16 @@ int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_sol
         }
     }
     const bool exchanges = fb.coop_c > 1 || fb.all_c > 1;
+    inf->kernel = fb.all_c >= 1 ? EVC_KERNEL_FUSED_ALL
+                  : ((c_override == 0 && fused_res_supported(d.N, o.eps_mode, exact_div)) ? EVC_KERNEL_FUSED_RES
+                                                                                          : EVC_KERNEL_FUSED_MU);
+    inf->members = fb.all_c >= 1 ? fb.all_c : fb.coop_c;
+    inf->exchange = exchanges ? 1 : 0;
     int* coop_abort = fb.coop_cnt + COOP_MAX_TILES;
-    // tests only (environment, not part of the ABI): EVC_TEST_COOP_ABORT=k raises the abort flag in front of the
-    // k-th launch of the iteration loop (0: the call starts with it raised), as a timed-out wait would; the call
-    // then takes the caller's retry path after a partially completed solve
-    const char* fake = getenv("EVC_TEST_COOP_ABORT");
-    const int fake_at = fake ? atoi(fake) : -1;
+    // tests only (evc_solve_opts.test_abort_at, 0 in production): k > 0 raises the abort flag in front of the k-th
+    // launch of the iteration loop (-1: the call starts with it raised), as a timed-out wait would; the call then
+    // takes the caller's retry path after a partially completed solve
+    const int fake_at = o.test_abort_at < 0 ? 0 : (o.test_abort_at > 0 ? o.test_abort_at : -1);
     if (exchanges) HIP_TRY(hipMemsetAsync(coop_abort, fake_at == 0 ? 1 : 0, sizeof(int), s));
     int first = 1, launch_no = 0;
     if (o.check_every > 0 && o.stop_rule == EVC_STOP_SKLEARN) {   // error_at_init
@@ -254,6 +263,7 @@ int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_sol
         }
         if (exchanges && fake_at > 0 && launch_no == fake_at) HIP_TRY(hipMemsetAsync(coop_abort, 1, sizeof(int), s));
         ++launch_no;
+        ++inf->launches;
         HIP_TRY(fused_iterate(w.fl, fb, w.u, d.N, d.T_, n, first, check ? 1 : 0, w.err2, o.eps_mode,
                               o.eps, o.l1, c_override, o.stop_rule == EVC_STOP_NONE ? 1 : 0, o.loss, exact_div, s));
         first = 0;
@@ -283,7 +293,7 @@ int finish_fused<double>(const Workspace<double>& w, const Dims& d, const evc_so
         // Bt[n][mb] (zero padded to 32 bins) -> B's V'-operand fragments -> pre-pass -> Y
         HIP_TRY(copy2d<double>(static_cast<const double*>(y->B), y->ldb, d.N, y->Mb, fm ? 0 : 1, w.Bt, 32, d.Np,
                                32, 0, s));
-        HIP_TRY(fused_pack_dict(w.flB, w.B1p, w.B2p, w.Bt, 32, s));
+        HIP_TRY(fused_pack_dict(w.flB, w.B1p, w.B2p, w.Bt, 32, d.Np, s));
         HIP_TRY(fused_synthesize(w.flB, w.B2p, w.fb.Hp, w.Yp, w.u, d.N, d.T_, y->Mb,
                                  static_cast<double*>(y->Y), y->ldy, fm ? 1 : 0, s));
         return ST_OK;
@@ -292,10 +302,21 @@ int finish_fused<double>(const Workspace<double>& w, const Dims& d, const evc_so
     return synth_rows<double>(w.H0, d.Np, *y, d.N, d.T_, fm, s);
 }
 
+template <typename T> int gemm_kernel_id() {
+#if defined(EVC_DIAG_GEMM_V1)
+    return EVC_KERNEL_GEMM_NT;
+#elif defined(EVC_DIAG_GEMM2_F64)
+    return EVC_KERNEL_GEMM2;
+#else
+    return sizeof(T) == 4 ? EVC_KERNEL_GEMM2 : EVC_KERNEL_GEMM_NT;
+#endif
+}
+
 template <typename T>
 int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int ldh, int M, int N,
                 int T_, const int* utt_offsets, int n_utt, const evc_solve_opts& o, void* ws,
-                size_t ws_bytes, int* n_iter_out, double* err_out, const SynthArgs* y, hipStream_t s) {
+                size_t ws_bytes, int* n_iter_out, double* err_out, const SynthArgs* y, hipStream_t s,
+                evc_solve_info* inf) {
     const T* A = static_cast<const T*>(A_);
     const T* X = static_cast<const T*>(X_);
     T* H = static_cast<T*>(H_);
@@ -341,7 +362,7 @@ int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int 
             int exported = 0;
             // (with caller-given start values the abort flag is read before anything goes to the caller's H: no
             // direct export then)
-            int st = solve_fused(w, d, oo, n_utt, s, &coop_used, check_first ? (T*)nullptr : H, ldh, &exported);
+            int st = solve_fused(w, d, oo, n_utt, s, &coop_used, check_first ? (T*)nullptr : H, ldh, &exported, inf);
             if (st) return st;
             if (coop_used && check_first) {
                 st = coop_timed_out(w, s, &aborted);
@@ -358,6 +379,8 @@ int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int 
             if (!aborted) break;
             if (attempt == 1) return ST_COOP_TIMEOUT;      // cannot happen: the redo is not cooperative
             oo.reserved |= 4;
+            oo.test_abort_at = 0;
+            inf->redo = 1;
             HIP_TRY(utt_setup(w.u, n_utt, T_, d.Tp, o.iters, s));
             if (o.init_mode == EVC_INIT_SKLEARN) HIP_TRY(utt_sklearn_h0<T>(w.Xt, d.Mk, M, N, w.u, n_utt, s));
             else if (o.init_mode == EVC_INIT_CONST) HIP_TRY(utt_const_h0(w.u, n_utt, o.init_value, s));
@@ -397,6 +420,9 @@ int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int 
     ep.P = w.Pt; ep.frame_utt = w.u.frame_utt; ep.active = w.u.active; ep.ldh = d.Np;
     ep.N = N; ep.T_ = T_; ep.eps_mode = o.eps_mode; ep.eps = (T)o.eps; ep.l1 = (T)o.l1; ep.kl = kl ? 1 : 0;
 
+    inf->kernel = gemm_kernel_id<T>();
+    inf->members = 1;
+    inf->launches = o.iters * (gram ? 1 : 2);
     if (o.ev_loop_start) HIP_TRY(hipEventRecord((hipEvent_t)o.ev_loop_start, s));
     for (int it = 1; it <= o.iters; ++it) {
         if (algo == EVC_ALGO_LITERAL) {   // pymf nmf.py:68-69 recomputes both every iteration
@@ -503,7 +529,8 @@ size_t evc_workspace_bytes(int M, int Mb, int N, int T, int n_utt, int dtype, in
 
 static int solve_f32_on_f64(const void* A, int lda, const void* X, int ldx, void* H, int ldh, int M, int N, int T,
                             const int* utt_offsets, int n_utt, const evc_solve_opts& o, void* ws, size_t ws_bytes,
-                            int* n_iter_out, double* err_out, const SynthArgs* y, hipStream_t s) {
+                            int* n_iter_out, double* err_out, const SynthArgs* y, hipStream_t s,
+                            evc_solve_info* inf) {
     const bool fm = (o.layout == EVC_FRAME_MAJOR);
     const int Mb = y ? y->Mb : 0;
     const size_t stage = f32_staging_bytes(M, Mb, N, T);
@@ -530,7 +557,7 @@ static int solve_f32_on_f64(const void* A, int lda, const void* X, int ldx, void
     o64.dtype = EVC_F64;
     const int st = solve_typed<double>(A64, (int)aC, X64, (int)xC, H ? H64 : nullptr, (int)hC, M, N, T, utt_offsets,
                                        n_utt, o64, static_cast<char*>(ws) + stage, ws_bytes - stage, n_iter_out,
-                                       err_out, y ? &y64 : nullptr, s);
+                                       err_out, y ? &y64 : nullptr, s, inf);
     if (st) return st;
     if (H) HIP_TRY((cvt2d<double, float>(H64, hC, hR, hC, static_cast<float*>(H), ldh, s)));
     if (y) HIP_TRY((cvt2d<double, float>(Y64, yC, yR, yC, static_cast<float*>(y->Y), y->ldy, s)));
@@ -560,6 +587,7 @@ static int solve_checked(const void* A, int lda, const void* X, int ldx, void* H
         if (o.algo == EVC_ALGO_GRAM || o.algo == EVC_ALGO_LITERAL) return ST_UNSUPPORTED;
     }
     if (y && y->Mb < 1) return ST_BADARG;
+    if (o.info && o.info->struct_bytes != (int)sizeof(evc_solve_info)) return ST_BADARG;
     if (T == 0) {
         if (n_iter_out) for (int i = 0; i < n_utt; ++i) n_iter_out[i] = 0;
         return ST_OK;
@@ -578,14 +606,22 @@ static int solve_checked(const void* A, int lda, const void* X, int ldx, void* H
         return ST_BADARG;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    evc_solve_info inf{};
+    int st;
     if (o.dtype == EVC_F64)
-        return solve_typed<double>(A, lda, X, ldx, H, ldh, M, N, T, utt_offsets, n_utt, o, workspace,
-                                   workspace_bytes, n_iter_out, err_out, y, s);
-    if (f32_rides_f64(M, N, T, o.algo, o.reserved))
-        return solve_f32_on_f64(A, lda, X, ldx, H, ldh, M, N, T, utt_offsets, n_utt, o, workspace, workspace_bytes,
-                                n_iter_out, err_out, y, s);
-    return solve_typed<float>(A, lda, X, ldx, H, ldh, M, N, T, utt_offsets, n_utt, o, workspace,
-                              workspace_bytes, n_iter_out, err_out, y, s);
+        st = solve_typed<double>(A, lda, X, ldx, H, ldh, M, N, T, utt_offsets, n_utt, o, workspace,
+                                 workspace_bytes, n_iter_out, err_out, y, s, &inf);
+    else if (f32_rides_f64(M, N, T, o.algo, o.reserved))
+        st = solve_f32_on_f64(A, lda, X, ldx, H, ldh, M, N, T, utt_offsets, n_utt, o, workspace, workspace_bytes,
+                              n_iter_out, err_out, y, s, &inf);
+    else
+        st = solve_typed<float>(A, lda, X, ldx, H, ldh, M, N, T, utt_offsets, n_utt, o, workspace,
+                                workspace_bytes, n_iter_out, err_out, y, s, &inf);
+    if (o.info && o.info->struct_bytes == (int)sizeof(evc_solve_info)) {
+        inf.struct_bytes = (int)sizeof(evc_solve_info);
+        *o.info = inf;
+    }
+    return st;
 }
 
 int evc_nmf_solve(const void* A, int lda, const void* X, int ldx, void* H, int ldh, int M, int N,

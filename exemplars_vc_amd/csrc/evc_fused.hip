@@ -34,7 +34,9 @@ namespace evc {
 // A1p[j][s/2][l][s&1]      = A[bin_of(s, l>>4)][16 j + 4 (l&3) + ((l&15)>>2)]   (A-operand of D and P;
 //                            s padded to an even count, the pad is zero)
 // A2p[j][u][r/2][l][r&1]   = A[16 u + (l&15)][16 j + 4 (l>>4) + r]              (A-operand of V')
-__global__ void k_pack_dict(const double* __restrict__ At, int ldA, int NT, int msteps, int mtiles,
+// At has n_rows rows (zero beyond the true N); exemplar slots from n_rows on - the tile count may be padded past
+// the array, see fused_layout - are written as zeros, never read.
+__global__ void k_pack_dict(const double* __restrict__ At, int ldA, int n_rows, int NT, int msteps, int mtiles,
                             double* __restrict__ A1p, double* __restrict__ A2p) {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int msp = (msteps + 1) & ~1;
@@ -44,13 +46,13 @@ __global__ void k_pack_dict(const double* __restrict__ At, int ldA, int NT, int 
         const long j = (gid >> 7) / (msp / 2);
         const int i = l & 15;
         const long n = 16 * j + 4 * (i & 3) + (i >> 2);
-        if (A1p) A1p[gid] = s < msteps ? At[n * ldA + bin_of(s, l >> 4)] : 0.0;
+        if (A1p) A1p[gid] = (s < msteps && n < n_rows) ? At[n * ldA + bin_of(s, l >> 4)] : 0.0;
     } else if (gid < n1 + n2) {
         const long g = gid - n1;
         const int e = g & 1, l = (g >> 1) & 63, r = 2 * (int)((g >> 7) & 1) + e, u = (g >> 8) % mtiles;
         const long j = (g >> 8) / mtiles;
         const long n = 16 * j + 4 * (l >> 4) + r;
-        if (A2p) A2p[g] = At[n * ldA + 16 * u + (l & 15)];
+        if (A2p) A2p[g] = n < n_rows ? At[n * ldA + 16 * u + (l & 15)] : 0.0;
     }
 }
 
@@ -407,10 +409,10 @@ FusedLayout fused_layout(int M, int N, int T_) {
     return f;
 }
 
-hipError_t fused_pack_dict(const FusedLayout& f, double* A1p, double* A2p, const double* At, int ldA,
+hipError_t fused_pack_dict(const FusedLayout& f, double* A1p, double* A2p, const double* At, int ldA, int n_rows,
                            hipStream_t s) {
     const long n = (long)f.a1 + (long)f.a2;
-    hipLaunchKernelGGL(k_pack_dict, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, At, ldA, f.NT, f.msteps,
+    hipLaunchKernelGGL(k_pack_dict, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, At, ldA, n_rows, f.NT, f.msteps,
                        f.mtiles, A1p, A2p);
     return hipGetLastError();
 }

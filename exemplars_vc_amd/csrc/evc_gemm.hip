@@ -219,10 +219,16 @@ hipError_t sum_slabs(const T* part, long slab, int splits, T* C, hipStream_t s) 
 
 // Which generation of the contraction kernel serves a call: k_gemm2 for float32 (77 against 65 Tflop/s on the
 // STFT flow); float64 stays on k_gemm_nt, which k_gemm2 does not beat (its 64-cycle MFMAs hide what k_gemm2
-// removes).  EVC_GEMM_V1 / EVC_GEMM2_F64 in the environment force one or the other (A/B timing).
+// removes).  Diagnostic builds (-DEVC_DIAG_GEMM_V1 / -DEVC_DIAG_GEMM2_F64) force one or the other for A/B timing;
+// the shipped library reads nothing from the environment.
 template <typename T> static bool use_gemm2() {
-    static const bool v1 = getenv("EVC_GEMM_V1") != nullptr, v2d = getenv("EVC_GEMM2_F64") != nullptr;
-    return !v1 && (sizeof(T) == 4 || v2d);
+#if defined(EVC_DIAG_GEMM_V1)
+    return false;
+#elif defined(EVC_DIAG_GEMM2_F64)
+    return true;
+#else
+    return sizeof(T) == 4;
+#endif
 }
 
 template <typename T>

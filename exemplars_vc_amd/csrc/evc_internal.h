@@ -187,8 +187,9 @@ struct FusedBuffers {
 bool fused_supported(int M, int N, int T_, int dtype);
 FusedLayout fused_layout(int M, int N, int T_);
 // At[n][m] / Xt[t][m]: the zero-padded frames-as-rows workspace arrays
-// (either destination may be NULL: only the other fragment order is written)
-hipError_t fused_pack_dict(const FusedLayout& f, double* A1p, double* A2p, const double* At, int ldA,
+// (either destination may be NULL: only the other fragment order is written); At has n_rows rows: the exemplar
+// slots of the (possibly further padded) tile grid beyond them are written as zeros
+hipError_t fused_pack_dict(const FusedLayout& f, double* A1p, double* A2p, const double* At, int ldA, int n_rows,
                            hipStream_t s);
 hipError_t fused_pack_frames(const FusedLayout& f, double* Xp, const double* Xt, int ldx, hipStream_t s);
 // rsum[m] = sum_n At[n][m] for m < M (fixed order), 0 for M <= m < 32

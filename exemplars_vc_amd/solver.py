@@ -167,7 +167,7 @@ def _solve(A, X, H0, B, *, layout="bin_major", iters=100, eps_mode="add", eps=No
            stop_rule="none", tol=0.0, utt_offsets: Optional[Sequence[int]] = None,
            dtype=None, device=None, info=False, out=None, loop_events=None,
            fused=True, fused_c=0, want_h=True, out_y=None, loss="frobenius", exact_div=False,
-           cooperative=True, all_resident=True, _fake_coop_timeout=False):
+           cooperative=True, all_resident=True, _fake_coop_timeout=False, solve_info=None):
     torch = _torch()
     device = require_device(device)
     L = _lib.lib()
@@ -237,10 +237,13 @@ def _solve(A, X, H0, B, *, layout="bin_major", iters=100, eps_mode="add", eps=No
     opts.reserved = ((0 if fused else _lib.FLAG_NO_FUSED) | (_lib.FLAG_EXACT_DIV if exact_div else 0)
                      | (0 if cooperative else _lib.FLAG_NO_EXCHANGE)
                      | (0 if all_resident else _lib.FLAG_NO_ALL_RESIDENT) | ((int(fused_c) & 0xff) << 8))
-    fake = _fake_coop_timeout is not False and _fake_coop_timeout is not None
-    if fake:    # tests: the library reads this from the environment, it is not part of the ABI.  True: the call starts
-        # with the abort flag raised; an int k > 0: it is raised in front of the k-th launch of the iteration loop
-        os.environ["EVC_TEST_COOP_ABORT"] = "0" if _fake_coop_timeout is True else str(int(_fake_coop_timeout))
+    if _fake_coop_timeout is not False and _fake_coop_timeout is not None:
+        # tests (evc_solve_opts.test_abort_at).  True: the call starts with the abort flag raised; an int k > 0: it is
+        # raised in front of the k-th launch of the iteration loop
+        opts.test_abort_at = -1 if _fake_coop_timeout is True else int(_fake_coop_timeout)
+    sinfo = _lib.SolveInfo()
+    sinfo.struct_bytes = C.sizeof(_lib.SolveInfo)
+    opts.info = C.addressof(sinfo)
     if loop_events is not None:     # (torch.cuda.Event, torch.cuda.Event), already created
         opts.ev_loop_start = int(loop_events[0].cuda_event)
         opts.ev_loop_stop = int(loop_events[1].cuda_event)
@@ -264,8 +267,6 @@ def _solve(A, X, H0, B, *, layout="bin_major", iters=100, eps_mode="add", eps=No
                 A_d.data_ptr(), _ld(A_d), X_d.data_ptr(), _ld(X_d), B_d.data_ptr(), _ld(B_d),
                 h_ptr, h_ld, Y_d.data_ptr(), _ld(Y_d), M, Mb, N, T, off_ptr, n_utt, C.byref(opts),
                 ws.data_ptr(), ws.numel(), ni_p, er_p, C.c_void_p(stream))
-    if fake:
-        os.environ.pop("EVC_TEST_COOP_ABORT", None)
     _lib.check(st, "evc_nmf_solve" if B is None else "evc_nmf_convert")
     to_np = x_np and out is None
     H_out = None if H_d is None else (_to_host(H_d) if to_np else H_d)
@@ -273,7 +274,13 @@ def _solve(A, X, H0, B, *, layout="bin_major", iters=100, eps_mode="add", eps=No
     if B is not None:
         res.append(_to_host(Y_d) if (x_np and out_y is None) else Y_d)
     if info:
-        res.append({"n_iter": n_iter, "err": err})
+        res.append({"n_iter": n_iter, "err": err, "kernel": _lib.KERNEL_NAMES.get(sinfo.kernel, str(sinfo.kernel)),
+                    "members": int(sinfo.members), "launches": int(sinfo.launches), "redo": int(sinfo.redo),
+                    "exchange": int(sinfo.exchange), "prepared": int(sinfo.prepared)})
+    if solve_info is not None:      # caller-supplied dict: filled without the synchronisation info=True implies
+        solve_info.update(kernel=_lib.KERNEL_NAMES.get(sinfo.kernel, str(sinfo.kernel)), members=int(sinfo.members),
+                          launches=int(sinfo.launches), redo=int(sinfo.redo), exchange=int(sinfo.exchange),
+                          prepared=int(sinfo.prepared))
     return res[0] if len(res) == 1 else tuple(res)
 
 

@@ -106,6 +106,7 @@ enum { EVC_LOSS_FROBENIUS = 0, EVC_LOSS_KL = 1 };
  *   NO_ALL_RESIDENT  keep k_fused_all out (k_fused_res, with its cooperative launch for few frame tiles) */
 enum { EVC_FLAG_NO_FUSED = 1, EVC_FLAG_EXACT_DIV = 2, EVC_FLAG_NO_EXCHANGE = 4, EVC_FLAG_NO_ALL_RESIDENT = 16 };
 
+struct evc_solve_info;
 typedef struct evc_solve_opts {
     int struct_bytes;  /* sizeof(evc_solve_opts), for forward compatibility */
     int dtype;         /* EVC_F64 | EVC_F32 */
@@ -119,7 +120,10 @@ typedef struct evc_solve_opts {
     int reserved;      /* flags, 0 = defaults: an OR of EVC_FLAG_* (below); bits 8..15: tuning only - 1 | 2 force the
                           general streamed kernel with that many frame tiles per workgroup */
     int loss;          /* EVC_LOSS_* */
-    int reserved2;     /* 0 */
+    int test_abort_at; /* 0 in production.  Tests only: k > 0 pretends, in front of the k-th launch of the iteration
+                          loop, that a workgroup gave up waiting for its peers (the abort flag is raised as a timed-out
+                          wait would raise it); -1: the call starts with the flag raised.  The solve then takes the
+                          documented redo path and evc_solve_info.redo reports 1. */
     double eps;        /* guard value for eps_mode */
     double l1;         /* added to the denominator (sklearn l1_reg_W = M*alpha_W*l1_ratio) */
     double tol;        /* threshold of stop_rule */
@@ -129,7 +133,33 @@ typedef struct evc_solve_opts {
      * that kernel live with HIP events. */
     void* ev_loop_start;
     void* ev_loop_stop;
+    /* optional evc_solve_info* (host, caller-owned, struct_bytes set by the caller; NULL = not wanted): filled before the
+     * call returns with what the library actually ran.  No extra synchronisation: `redo` is known from the round trip an
+     * exchanging solve performs anyway. */
+    struct evc_solve_info* info;
 } evc_solve_opts;
+
+/* the kernel that carried the iteration loop of a solve */
+enum {
+    EVC_KERNEL_NONE = 0,
+    EVC_KERNEL_GEMM_NT = 1,     /* generic path, k_gemm_nt x2 per iteration (float64, M > 32; GRAM / LITERAL) */
+    EVC_KERNEL_GEMM2 = 2,       /* generic path, k_gemm2 x2 per iteration (float32) */
+    EVC_KERNEL_FUSED_MU = 3,    /* k_fused_mu: fused FACTORED, everything streamed (M <= 32) */
+    EVC_KERNEL_FUSED_RES = 4,   /* k_fused_res: half of H register-resident (members > 1: its cooperative launch) */
+    EVC_KERNEL_FUSED_ALL = 5,   /* k_fused_all: H and P register-resident, `members` workgroups per frame tile */
+    EVC_KERNEL_FUSED_WIDE = 6   /* k_fused_wide: fused FACTORED for M > 32, task queue over (frame group, exemplar range) */
+};
+
+typedef struct evc_solve_info {
+    int struct_bytes;  /* in: sizeof(evc_solve_info) */
+    int kernel;        /* EVC_KERNEL_* of the (last) attempt whose results were delivered */
+    int members;       /* workgroups / tasks sharing one frame tile or frame group (1: no sharing) */
+    int launches;      /* kernel launches of the iteration loop (all attempts) */
+    int redo;          /* 1: an exchange wait ran out and the solve was redone on kernels without exchange */
+    int exchange;      /* 1: the delivered results come from a kernel whose workgroups exchange partial sums in a launch */
+    int prepared;      /* 1: the dictionary came from an evc_dict_prepare image (no per-call import / packing) */
+    int reserved;
+} evc_solve_info;
 
 int evc_version(void);
 const char* evc_strerror(int status);

@@ -66,3 +66,41 @@ def test_presets_and_flop_counts():
     assert bench.algorithmic_flops_per_frame(25, 4096, 100, 25, "factored") == 42598400
     assert bench.loop_flops_per_frame(25, 4096, 100, "factored") == 100 * (4 * 25 * 4096 + 3 * 4096)
     assert bench.cpu_sample_frames(4096, 688) == 688 and bench.cpu_sample_frames(16384, 688) == 43
+
+
+def test_gpus_flag_spawns_a_launcher_child_and_relays_its_status():
+    """`python bench.py --gpus N` without a launcher: the parent builds the torch.distributed.run command (one rank
+    per GPU, rendezvous on 127.0.0.1), runs it as a child and hands back its exit status; nothing is exec'ed."""
+    import bench
+    cmd = bench.launcher_command(["--gpus", "4", "--steps", "3"], 4, 29511, python="python")
+    assert cmd[:3] == ["python", "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-5].endswith("bench.py") and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    seen = {}
+
+    class Done:
+        returncode = 7
+
+    def fake_run(c, env):
+        seen["cmd"], seen["env"] = c, env
+        return Done()
+
+    assert bench.spawn_ranks(["--gpus", "2"], 2, run=fake_run) == 7
+    assert "--nproc-per-node=2" in seen["cmd"] and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    p = bench.free_port()
+    assert 1024 < p < 65536
+
+
+def test_c4_is_one_set_split_over_the_ranks():
+    import bench
+    lens = [bench.C4_LENGTHS[i % len(bench.C4_LENGTHS)] for i in range(162)]
+    assert sum(lens) == 109206
+    for world in (1, 2, 4, 8):
+        shards = [bench.shard_of_rank(lens, world, r) for r in range(world)]
+        assert sorted(i for s in shards for i in s) == list(range(162))
+        loads = [sum(lens[i] for i in s) for s in shards]
+        assert max(loads) - min(loads) <= max(lens)          # LPT: even to within one utterance
+    # strong scaling: the job's value counts the set once, whatever the number of ranks
+    assert bench.job_throughput(8, 13000, 5, 2.0, total_units=109206) == pytest.approx(109206 * 5 / 2.0)
+    assert bench.job_throughput(8, 1000, 5, 2.0) == pytest.approx(8 * 1000 * 5 / 2.0)

@@ -32,8 +32,16 @@ def test_struct_mirror_matches_header_fields():
     hdr = open(os.path.join(ROOT, "include", "evc.h")).read()
     body = hdr[hdr.index("typedef struct evc_solve_opts {"):hdr.index("} evc_solve_opts;")]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-    fields = re.findall(r"\b(?:int|double|void\*)\s+([a-z_0-9]+);", body)
+    fields = re.findall(r"\b(?:int|double|void\*|struct evc_solve_info\*)\s+([a-z_0-9]+);", body)
     assert fields == [f[0] for f in _lib.SolveOpts._fields_]
+    body = hdr[hdr.index("typedef struct evc_solve_info {"):hdr.index("} evc_solve_info;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    assert re.findall(r"\bint\s+([a-z_0-9]+);", body) == [f[0] for f in _lib.SolveInfo._fields_]
+    assert C.sizeof(_lib.SolveInfo) == 32
+    # kernel ids of the header <-> the names the Python side reports
+    ids = dict((n.lower(), int(v)) for n, v in re.findall(r"EVC_KERNEL_([A-Z_0-9]+) = (\d+)", hdr))
+    assert ids == {"none": 0, "gemm_nt": 1, "gemm2": 2, "fused_mu": 3, "fused_res": 4, "fused_all": 5, "fused_wide": 6}
+    assert all(_lib.KERNEL_NAMES[v] in ("none", "k_" + n) for n, v in ids.items())
 
 
 def test_strerror_and_workspace_queries():

@@ -315,3 +315,72 @@ def test_kl_update_on_the_all_resident_kernel(M, N):
     res2, info_r = evc.solve_activations(W, X, check_every=5, info=True, all_resident=False, **kw)
     assert_close64(got2, want, "KL with error trace")
     np.testing.assert_allclose(info["err"], info_r["err"], rtol=1e-9, equal_nan=True)
+
+
+def test_the_library_reports_which_kernel_ran():
+    """evc_solve_info (include/evc.h): the kernel, the members per frame tile, the launches and whether a redo
+    happened come from the library, not from a guess about the shape (missing item 4)."""
+    import exemplars_vc_amd as evc
+    o = oracle()
+    p = o.synth_problem(25, 4096, 688 * 3, seed=11)
+    kw = dict(iters=20, eps_mode="zero_replace", init="sklearn", info=True)
+    _, i = evc.solve_activations(p["A"], p["X"], **kw)                      # C2's shape: the all-resident kernel
+    assert (i["kernel"], i["members"], i["redo"], i["exchange"], i["launches"]) == ("k_fused_all", 8, 0, 1, 1), i
+    _, i = evc.solve_activations(p["A"], p["X"], cooperative=False, **kw)   # no exchange allowed
+    assert i["kernel"] in ("k_fused_res", "k_fused_mu") and i["members"] == 1 and i["exchange"] == 0, i
+    _, i = evc.solve_activations(p["A"], p["X"], check_every=10, stop_rule="sklearn", tol=1e-9, **kw)
+    assert i["launches"] == 2 and i["redo"] == 0, i                         # one launch per 10 iterations
+    _, i = evc.solve_activations(p["A"], p["X"], _fake_coop_timeout=True, **kw)
+    assert i["redo"] == 1 and i["exchange"] == 0 and i["launches"] == 2, i
+    _, i = evc.solve_activations(p["A"], p["X"], fused=False, **kw)
+    assert i["kernel"] == "k_gemm_nt" and i["launches"] == 40, i
+    q = o.synth_problem(201, 256, 64, seed=3)
+    _, i = evc.solve_activations(q["A"].astype(np.float32), q["X"].astype(np.float32), fused=False, **kw)
+    assert i["kernel"] == "k_gemm2", i
+
+
+@pytest.mark.parametrize("loss", ["frobenius", "kl"])
+def test_tile_grid_padded_past_the_dictionary_array(loss):
+    """N = 3600: the exemplar tile grid is padded to whole 512-exemplar members (4096 slots) while the imported
+    dictionary has 3712 rows: the packing must write zeros for the slots beyond the array instead of
+    reading past it.  The workspace is pre-filled with NaN bytes so that anything read from beyond shows."""
+    import torch
+    import exemplars_vc_amd as evc
+    from exemplars_vc_amd import solver
+    o = oracle()
+    M, N, T, K = 25, 3600, 96, 30
+    p = o.synth_problem(M, N, T, seed=8)
+    nbytes = solver.workspace_bytes(M, N, T, Mb=M)
+    dev = torch.device("cuda", 0)
+    with solver._workspace(nbytes, dev) as ws:       # poison the scratch buffer the next call will carve
+        ws.fill_(0xFF)
+    if loss == "kl":
+        X_rows, W_rows = np.ascontiguousarray(p["X"].T), np.ascontiguousarray(p["A"].T)
+        want = o.sklearn_mu_fixed_dictionary_kl(X_rows, W_rows, K, 0.0)[0].T
+        H, Y = evc.convert(p["A"], p["X"], p["B"], iters=K, eps_mode="zero_replace", init="sklearn", loss="kl")
+    else:
+        want = o.sklearn_mu_fixed_dictionary(np.ascontiguousarray(p["X"].T), np.ascontiguousarray(p["A"].T), K, 0.0)[0].T
+        H, Y = evc.convert(p["A"], p["X"], p["B"], iters=K, eps_mode="zero_replace", init="sklearn")
+    assert np.isfinite(H).all() and np.isfinite(Y).all()
+    np.testing.assert_allclose(H, want, rtol=1e-8, atol=1e-300)
+    np.testing.assert_allclose(Y, p["B"] @ want, rtol=1e-8)
+
+
+def test_bench_gpus_flag_starts_the_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher in the environment starts two ranks itself (here both on the one
+    card, over gloo) and reports them: n_gpus, ranks_seen, one rate per rank; C4 is one set split over the ranks."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-device", "--dist-backend", "gloo",
+           "--steps", "2", "--warmup", "1", "--no-cpu", "--no-pcie", "--config", "C4"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    r = json.loads(line)
+    assert r["n_gpus"] == 2 and r["ranks_seen"] == 2 and len(r["frames_per_s_per_rank"]) == 2, r
+    assert r["scaling"] == "strong" and r["config"]["frames_per_step_all_gpus"] == 109206, r
+    assert r["config"]["frames_per_gpu"] < 109206 * 0.51, r
+    assert r["redo_count"] == 0 and "k_fused_all" in r["config"]["kernel"], r
+    assert r["value"] == pytest.approx(109206 * 2 / (r["ms_per_step"] * 2 / 1e3), rel=1e-6)

@@ -656,6 +656,8 @@ def test_cooperative_timeout_falls_back_to_one_workgroup_per_tile():
         # second configuration runs one launch per 10 iterations), i.e. the redo follows a partly completed solve
         for when in ((True, 2) if kw.get("check_every") else (True,)):
             got, ig = evc.solve_activations(p["A"], p["X"], h0, _fake_coop_timeout=when, info=True, **kw)
+            assert ig["redo"] == 1 and ig["exchange"] == 0, ig      # the library says that it redid the solve
+            assert iw["redo"] == 0
             assert np.array_equal(got, want), when
             assert np.array_equal(ig["n_iter"], iw["n_iter"]), when
             assert np.array_equal(np.nan_to_num(ig["err"]), np.nan_to_num(iw["err"])), when
