@@ -302,6 +302,140 @@ int finish_fused<double>(const Workspace<double>& w, const Dims& d, const evc_so
     return synth_rows<double>(w.H0, d.Np, *y, d.N, d.T_, fm, s);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// The wide fused path (float32, 32 < M <= 208, FACTORED): k_fused_wide (evc_wide.hip).  One launch per
+// `check_every` iterations (a single launch when no residual is wanted); iteration 0 forms P and V = A H0.
+// ------------------------------------------------------------------------------------------------------
+struct WideWs {
+    float *At, *Akl, *Xt, *H0;
+    WideBuffers fb;
+    WideCaps caps;
+    double* err2;
+    UttState u;
+    size_t bytes;
+};
+int device_cus() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+    return cus;
+}
+WideWs carve_wide(void* base, const Dims& d, int n_slots, int n_cus, bool with_synth, bool kl) {
+    WideWs w{};
+    Carver c{static_cast<char*>(base), 0};
+    w.caps = wide_caps(d.M, d.N, d.T_, n_cus);
+    w.At = c.take<float>((size_t)d.Np * d.Mk);
+    w.Akl = kl ? c.take<float>((size_t)d.Np * d.Mk) : nullptr;
+    w.Xt = c.take<float>((size_t)d.Tp * d.Mk);
+    w.H0 = with_synth ? c.take<float>((size_t)d.Tp * d.Np) : nullptr;
+    w.fb.Aw = c.take<float>(w.caps.aw);
+    w.fb.Xw = c.take<float>(w.caps.xw);
+    w.fb.Hw = c.take<float>(w.caps.hw);
+    w.fb.Pw = c.take<float>(w.caps.hw);
+    w.fb.Vpart = c.take<float>(w.caps.vpart);
+    w.fb.Vsum = c.take<float>(w.caps.vsum);
+    w.fb.ctl = c.take<unsigned>(w.caps.ctl);
+    w.err2 = c.take<double>(d.Tp);
+    w.u.frame_utt = c.take<int>(d.Tp);
+    w.u.offsets = c.take<int>(d.n_utt + 1);
+    w.u.active = c.take<int>(d.n_utt);
+    w.u.n_iter = c.take<int>(d.n_utt);
+    w.u.err_init = c.take<double>(d.n_utt);
+    w.u.err_prev = c.take<double>(d.n_utt);
+    w.u.h0 = c.take<double>(d.n_utt);
+    w.u.trace = c.take<double>((size_t)d.n_utt * n_slots);
+    w.u.n_slots = n_slots;
+    w.bytes = (c.off + 255) & ~size_t(255);
+    return w;
+}
+bool use_wide(int M, int N, int T_, int dtype, int algo, int reserved) {
+    return !(reserved & EVC_FLAG_NO_FUSED) && wide_supported(M, N, T_, dtype, algo);
+}
+
+int solve_wide(const float* A, int lda, const float* X, int ldx, float* H, int ldh, int M, int N, int T_,
+               const int* utt_offsets, int n_utt, const evc_solve_opts& o, void* ws, size_t ws_bytes,
+               int* n_iter_out, double* err_out, const SynthArgs* y, hipStream_t s, evc_solve_info* inf) {
+    const Dims d = make_dims(4, M, N, T_, n_utt, y ? y->Mb : 0);
+    const int n_slots = n_slots_for(o.iters, o.check_every);
+    if (n_slots > MAX_SLOTS) return ST_UNSUPPORTED;
+    const int n_cus = device_cus();
+    const bool kl = o.loss == EVC_LOSS_KL, fm = o.layout == EVC_FRAME_MAJOR;
+    WideWs w = carve_wide(ws, d, MAX_SLOTS, n_cus, true, true);
+    if (w.bytes > ws_bytes) return ST_WORKSPACE;
+    w.u.n_slots = n_slots;
+    // tuning / tests: reserved bits 8..15 = exemplar ranges per frame group, bits 16..19 = wavefronts per workgroup
+    const WideLayout fl = wide_layout(M, N, T_, n_cus, (o.reserved >> 8) & 0xff, (o.reserved >> 16) & 0xf);
+    if (!wide_fits(fl, w.caps)) return ST_WORKSPACE;
+
+    if (utt_offsets)
+        HIP_TRY(hipMemcpyAsync(w.u.offsets, utt_offsets, sizeof(int) * (n_utt + 1), hipMemcpyHostToDevice, s));
+    else
+        HIP_TRY(utt_single(w.u, T_, s));
+    HIP_TRY(utt_setup(w.u, n_utt, T_, d.Tp, o.iters, s));
+    HIP_TRY(copy2d<float>(A, lda, N, M, fm ? 0 : 1, w.At, d.Mk, d.Np, d.Mk, 0, s));
+    HIP_TRY(copy2d<float>(X, ldx, T_, M, fm ? 0 : 1, w.Xt, d.Mk, d.Tp, d.Mk, 0, s));
+    if (kl) HIP_TRY(kl_scale_dict<float>(w.At, d.Mk, M, d.Np, o.eps, w.Akl, s));
+    if (o.init_mode == EVC_INIT_SKLEARN) HIP_TRY(utt_sklearn_h0<float>(w.Xt, d.Mk, M, N, w.u, n_utt, s));
+    else if (o.init_mode == EVC_INIT_CONST) HIP_TRY(utt_const_h0(w.u, n_utt, o.init_value, s));
+    HIP_TRY(wide_pack_dict(fl, kl ? w.Akl : w.At, w.At, d.Mk, d.Np, w.fb.Aw, s));
+    HIP_TRY(wide_pack_x(fl, w.Xt, d.Mk, d.Tp, w.fb.Xw, s));
+    const int init_const = o.init_mode == EVC_INIT_GIVEN ? 0 : 1;
+    if (!init_const) HIP_TRY(wide_import_h(fl, w.fb.Hw, H, ldh, fm ? 1 : 0, T_, N, s));
+    HIP_TRY(wide_begin(fl, w.fb, s));
+    const int mode = kl ? 100 : o.eps_mode;
+
+    inf->kernel = EVC_KERNEL_FUSED_WIDE;
+    inf->members = fl.c;
+    inf->exchange = fl.c > 1 ? 1 : 0;
+    int next_it = 0;                 // first iteration not yet run (0 = the pass that forms P and V = A H0)
+    auto run_to = [&](int it_end) -> int {      // iterations [next_it, it_end)
+        if (it_end <= next_it) return 0;
+        HIP_TRY(wide_iterate(fl, w.fb, w.u, N, T_, next_it, it_end, mode, o.eps, o.l1, init_const, n_cus, s));
+        ++inf->launches;
+        next_it = it_end;
+        return 0;
+    };
+    auto check = [&](int c) -> int {
+        HIP_TRY(wide_err2(fl, w.fb, w.u, N, T_, next_it - 1, kl ? 1 : 0, o.eps, w.err2, s));
+        HIP_TRY(utt_check(w.err2, w.u, n_utt, c, o.check_every, o.stop_rule, o.tol, s));
+        return 0;
+    };
+    if (o.check_every > 0 && o.stop_rule == EVC_STOP_SKLEARN) {   // error_at_init, sklearn _nmf.py:827
+        int st = run_to(1);
+        if (st) return st;
+        st = check(0);
+        if (st) return st;
+    }
+    if (o.ev_loop_start) HIP_TRY(hipEventRecord((hipEvent_t)o.ev_loop_start, s));
+    int done = 0;
+    while (done < o.iters) {
+        int n = o.iters - done;
+        bool chk = false;
+        if (o.check_every > 0 && n >= o.check_every) { n = o.check_every; chk = true; }
+        int st = run_to(done + n + 1);
+        if (st) return st;
+        done += n;
+        if (chk) {
+            st = check(done / o.check_every);
+            if (st) return st;
+        }
+    }
+    {
+        int st = run_to(1);           // iters == 0: the start values still have to exist
+        if (st) return st;
+    }
+    if (o.ev_loop_stop) HIP_TRY(hipEventRecord((hipEvent_t)o.ev_loop_stop, s));
+    const int* abort = reinterpret_cast<const int*>(w.fb.ctl + 1);
+    if (H) HIP_TRY(wide_export_h(fl, w.fb.Hw, H, ldh, fm ? 1 : 0, T_, N, abort, s));
+    if (y) {
+        HIP_TRY(wide_export_h(fl, w.fb.Hw, w.H0, d.Np, 1, T_, N, abort, s));
+        int st = synth_rows<float>(w.H0, d.Np, *y, N, T_, fm, s);
+        if (st) return st;
+    }
+    return copy_back(w.u, n_utt, n_slots, n_iter_out, err_out, s);
+}
+
 template <typename T> int gemm_kernel_id() {
 #if defined(EVC_DIAG_GEMM_V1)
     return EVC_KERNEL_GEMM_NT;
@@ -518,6 +652,11 @@ size_t evc_workspace_bytes(int M, int Mb, int N, int T, int n_utt, int dtype, in
     if (dtype == EVC_F64) return workspace_typed<double>(M, Mb, N, T, n_utt, algo);
     if (dtype == EVC_F32) {
         size_t b = workspace_typed<float>(M, Mb, N, T, n_utt, algo);
+        if (wide_supported(M, N, T, dtype, algo == EVC_ALGO_AUTO ? EVC_ALGO_FACTORED : algo)) {
+            const Dims d = make_dims(4, M, N, T, n_utt, Mb);
+            const size_t wb = carve_wide(nullptr, d, MAX_SLOTS, device_cus(), true, true).bytes;
+            if (wb > b) b = wb;
+        }
         if (f32_rides_f64(M, N, T, algo, 0)) {
             const size_t c = f32_staging_bytes(M, Mb, N, T) + workspace_typed<double>(M, Mb, N, T, n_utt, algo);
             if (c > b) b = c;
@@ -614,6 +753,9 @@ static int solve_checked(const void* A, int lda, const void* X, int ldx, void* H
     else if (f32_rides_f64(M, N, T, o.algo, o.reserved))
         st = solve_f32_on_f64(A, lda, X, ldx, H, ldh, M, N, T, utt_offsets, n_utt, o, workspace, workspace_bytes,
                               n_iter_out, err_out, y, s, &inf);
+    else if (use_wide(M, N, T, o.dtype, o.algo == EVC_ALGO_AUTO ? EVC_ALGO_FACTORED : o.algo, o.reserved))
+        st = solve_wide(static_cast<const float*>(A), lda, static_cast<const float*>(X), ldx, static_cast<float*>(H),
+                        ldh, M, N, T, utt_offsets, n_utt, o, workspace, workspace_bytes, n_iter_out, err_out, y, s, &inf);
     else
         st = solve_typed<float>(A, lda, X, ldx, H, ldh, M, N, T, utt_offsets, n_utt, o, workspace,
                                 workspace_bytes, n_iter_out, err_out, y, s, &inf);

@@ -210,6 +210,42 @@ hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttS
                          int iters, int first, int write_err, double* err2, int eps_mode, double eps,
                          double l1, int c_req, int all_live_known, int loss, int exact_div, hipStream_t s);
 
+// ----- evc_wide.hip -----
+// Fused FACTORED kernel for wide spectra (32 < M <= 208 bins, float32): k_fused_wide, a task queue over
+// (iteration, frame group, exemplar range).
+struct WideLayout {
+    int MT;              // bin tiles of 16 (template instance: >= ceil(M / 16))
+    int W;               // wavefronts (= frame tiles of 16) per workgroup: 4 or 8
+    int NB;              // exemplar blocks of 16
+    int TT, G;           // frame tiles, frame groups of W tiles
+    int c, rmode;        // exemplar ranges per group; 1: a reduce task sums the partial V' (c > 4)
+    size_t aw, xw, hw, vpart, vsum;      // element counts (Pw has hw elements)
+};
+struct WideBuffers {
+    float *Aw, *Xw, *Hw, *Pw, *Vpart, *Vsum;
+    unsigned* ctl;       // [4 + 2 G]: ticket, abort flag, -, -, done[G], done_r[G]
+};
+bool wide_supported(int M, int N, int T_, int dtype, int algo);
+// c_req / w_req: 0 = automatic (tuning and tests: ranges per group, wavefronts per workgroup)
+WideLayout wide_layout(int M, int N, int T_, int n_cus, int c_req, int w_req);
+size_t wide_ctl_words(const WideLayout& f);
+struct WideCaps { size_t aw, xw, hw, vpart, vsum, ctl; int c_cap; };
+WideCaps wide_caps(int M, int N, int T_, int n_cus);
+bool wide_fits(const WideLayout& f, const WideCaps& k);
+// At1: the dictionary the numerator / denominator contraction uses (A, or A / colsum for KL), At2: A; exemplars as rows
+hipError_t wide_pack_dict(const WideLayout& f, const float* At1, const float* At2, int ld, int n_rows, float* Aw,
+                          hipStream_t s);
+hipError_t wide_pack_x(const WideLayout& f, const float* Xt, int ld, int rows, float* Xw, hipStream_t s);
+hipError_t wide_import_h(const WideLayout& f, float* Hw, const float* H, long ldh, int frame_major, int T_, int N,
+                         hipStream_t s);
+hipError_t wide_export_h(const WideLayout& f, const float* Hw, float* H, long ldh, int frame_major, int T_, int N,
+                         const int* abort, hipStream_t s);
+hipError_t wide_begin(const WideLayout& f, const WideBuffers& b, hipStream_t s);
+hipError_t wide_iterate(const WideLayout& f, const WideBuffers& b, const UttState& u, int N, int T_, int it_begin,
+                        int it_end, int mode, double eps, double l1, int init_const, int n_cus, hipStream_t s);
+hipError_t wide_err2(const WideLayout& f, const WideBuffers& b, const UttState& u, int N, int T_, int it, int kl,
+                     double eps, double* err2, hipStream_t s);
+
 // ----- evc_gl.hip -----
 size_t gl_workspace_bytes(long T_total, int n_utt, int F, int hop, int iters);
 int stft_frames(long L, int hop, bool center, int F);

@@ -1,0 +1,617 @@
+// k_fused_wide: the fused FACTORED multiplicative update for wide spectra (32 < M <= 208 bins, float32) - the shapes
+// the reference script really runs (|Re STFT|, M = 201: 04_align_n_nmf.py:315-326, config/config:12).
+//
+//   per iteration and frame:  D = A^T V (+ l1, + eps)      V = A H of the previous iteration
+//                             H' = H (.) P (/) guard(D)     P = A^T X, formed once
+//                             V' = A H'
+//
+// Who holds what.  A wavefront owns 16 frames.  Its V tile (M x 16: MT accumulator tiles, 52 registers at M = 201)
+// and the V' it accumulates never leave its registers inside a task: the accumulator layout of V' IS the B-operand
+// layout of the next D product (for the 16x16x4 f32 MFMA: lane = (q, frame), register r <-> row 4 q + r, which as a
+// B operand is k = q of k-step r), and the accumulator layout of D is the layout of the H tile and the B-operand
+// layout of V' += A_j H'_j.  No shuffle, no LDS round trip for V, D or H.  H and P stream through memory exactly
+// once per iteration as whole 1 KiB tiles in that accumulator order; the denominator never exists in memory.
+//
+// The dictionary is read from L2 once per WORKGROUP and iteration: the W wavefronts of a workgroup are W different
+// frame tiles sweeping the same exemplar blocks in lock step, and each block's two operand images (A-operand of
+// D: 16 exemplars x M bins, A-operand of V': M bins x 16 exemplars; 2 x MT KiB) are copied global -> LDS by
+// LDS-DMA (global_load_lds_dwordx4, no staging registers) one block ahead, into a double buffer; every fragment
+// read is a conflict-free 1 KiB ds_read_b128 that feeds four k-steps.  One workgroup barrier per block.
+//
+// Filling 256 CUs with few frames.  An utterance is 43 frame tiles, 16 utterances are 688: far fewer than the
+// 1024 SIMDs x 2.  So the exemplars of a frame group (W tiles) are split into c ranges, and the unit of work is a
+// TASK (iteration, frame group, range): sweep the range's blocks, publish the partial V' (MT KiB per wavefront).
+// Tasks are handed out by a ticket counter in a fixed global order (iteration-major), to however many workgroups
+// are resident.  A task of iteration i+1 waits, on a per-group counter, for the c tasks of iteration i of its
+// group - all of them hold EARLIER tickets, i.e. are running or done: no deadlock whatever the residency, no
+// cooperative launch, no rounds, and load balance over any batch size (the tail is one task at the very end of
+// the solve, not one per iteration).  Consumers sum the c partials in range order (bitwise reproducible).  With
+// many ranges (one or two utterances: c = 23...) a reduce task per (iteration, group, slice) sums a slice of the
+// c partials once, so that the traffic stays linear in c.
+//
+// Cross-workgroup visibility (guide: "Valid forms", first row of the measured table): every handed-off byte (V
+// partials and sums, H, P) is stored with sc1 (write-through) 16-byte stores and loaded with sc1 16-byte loads;
+// every storing wavefront drains its stores (s_waitcnt vmcnt(0)) before the workgroup barrier behind which ONE
+// lane adds to the group's counter; the consumer's lane 0 polls the counter with sc1 loads and the other
+// wavefronts load behind a barrier that lane then joins.  One workgroup per CU.
+#include "evc_internal.h"
+
+namespace evc {
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WIDE_KL = 100;                   // update mode besides the four eps modes
+constexpr long WIDE_SPIN_LIMIT = 1L << 24;     // polls of ~0.25 us: seconds; only a wedged device gets there
+
+struct WideArgs {
+    const float* Aw;         // [NB][2][MT][64][4]  per exemplar block: D-operand image, then V'-operand image
+    const float* Xw;         // [G W][MT][64][4]    frames in the V tile layout
+    float* Hw;               // [G W][NB][64][4]    activations in accumulator order
+    float* Pw;               // [G W][NB][64][4]    numerators A^T X
+    float* Vpart;            // [2][G][c][W][MT][64][4]
+    float* Vsum;             // [2][G][W][MT][64][4]   (reduce mode)
+    unsigned* ticket;        // next task of this launch
+    unsigned* done;          // [G] sweep tasks completed since the solve began
+    unsigned* done_r;        // [G] reduce tasks completed
+    int* abort;              // raised by a wait that ran out: everybody leaves, the export writes NaN
+    const int* frame_utt;    // [>= T_]
+    const int* active;       // [n_utt]
+    const double* h0;        // [n_utt] constant start value per utterance
+    int NB, TT, G, c, rmode;
+    int it_begin, it_end;    // iterations of this launch; iteration 0 forms P and V = A H0
+    int N, T_;
+    int mode;                // EVC_EPS_* or WIDE_KL
+    float eps, l1;
+    int init_const;          // 1: iteration 0 fills H with the utterances' constants (else Hw holds the given H0)
+};
+
+__device__ __forceinline__ f32x4 ld_sc1(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16));
+}
+__device__ __forceinline__ void st_sc1(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, byte_off, 0, 16);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void glds16(const float* g, char* lds) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+}
+__device__ __forceinline__ unsigned ld_ctr(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int MT, int W>
+__global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
+    constexpr int IMG = 2 * MT * 1024;                    // bytes of one block's two operand images
+    constexpr int NPIECE = 2 * MT;                        // 1 KiB LDS-DMA pieces per block
+    constexpr int PPW = (NPIECE + W - 1) / W;             // pieces per wavefront
+    constexpr unsigned TILE_B = MT * 1024;                // bytes of one V tile
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][IMG], then 16 bytes of control words
+    volatile unsigned* s_ctl = reinterpret_cast<volatile unsigned*>(smem + 2 * IMG);
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, i16 = lane & 15;
+    const unsigned GC = (unsigned)(a.G * a.c);
+    const unsigned per_it = a.rmode ? 2u * GC : GC;
+    const unsigned total = per_it * (unsigned)(a.it_end - a.it_begin);
+    const unsigned c = (unsigned)a.c;
+
+    unsigned nxt = 0;
+    if (tid == 0) {
+        nxt = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_ctl[0] = nxt;
+        s_ctl[1] = 1u;
+    }
+    __syncthreads();
+
+    // thread 0 polls a counter until it reaches `need`; false (for every thread) when the solve was aborted
+    auto wait_for = [&](const unsigned* ctr, unsigned need) -> bool {
+        if (tid == 0) {
+            unsigned ok = 1u;
+            long spins = 0;
+            while (ld_ctr(ctr) < need) {
+                __builtin_amdgcn_s_sleep(8);
+                ++spins;
+                if ((spins & 63) == 0 && __hip_atomic_load(a.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                    ok = 0u;
+                    break;
+                }
+                if (spins > WIDE_SPIN_LIMIT) {
+                    __hip_atomic_store(a.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0u;
+                    break;
+                }
+            }
+            s_ctl[1] = ok;
+        }
+        __syncthreads();
+        return s_ctl[1] != 0u;
+    };
+    // this wavefront's share of block jb's images -> LDS stage st (asynchronous: counted in vmcnt)
+    auto stage_block = [&](int jb, int st) {
+        const float* src = a.Aw + (size_t)jb * (IMG / 4) + lane * 4;
+        char* dst = smem + st * IMG;
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int p = w + k * W;
+            if (p < NPIECE) glds16(src + p * 256, dst + p * 1024);
+        }
+    };
+
+    for (;;) {
+        const unsigned tk = __builtin_amdgcn_readfirstlane(s_ctl[0]);
+        if (tk >= total) break;
+        __syncthreads();                       // everybody has read the ticket before thread 0 replaces it
+        if (tid == 0)                          // the next ticket is requested now and used at the end of this task
+            nxt = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned itl = tk / per_it, rem = tk - itl * per_it;
+        const int it = a.it_begin + (int)itl;
+        const bool reduce = rem >= GC;
+        const unsigned idx = reduce ? rem - GC : rem;
+        const int g = (int)(idx / c), e = (int)(idx - (unsigned)g * c);
+        const unsigned par = (unsigned)(it & 1);
+
+        if (reduce) {
+            // ---- reduce task: slice e of the group's V' = sum over the c ranges, in range order ----
+            if (!wait_for(a.done + g, c * (unsigned)(it + 1))) break;
+            const unsigned U = W * MT * 64;                       // 16-byte units of a group's partial
+            const unsigned lo = (unsigned)((unsigned long)e * U / c), hi = (unsigned)((unsigned long)(e + 1) * U / c);
+            const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.Vpart + ((size_t)(par * a.G + g) * c) * U * 4, c * U * 16u);
+            const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.Vsum + (size_t)(par * a.G + g) * U * 4, U * 16u);
+            for (unsigned un = lo + tid; un < hi; un += W * 64) {
+                f32x4 acc = ld_sc1(rin, un * 16u);
+                for (unsigned m = 1; m < c; ++m) acc += ld_sc1(rin, (m * U + un) * 16u);
+                st_sc1(rout, un * 16u, acc);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_fetch_add(a.done_r + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_ctl[0] = nxt;
+            }
+            __syncthreads();
+            continue;
+        }
+
+        // ---- sweep task (iteration it, frame group g, exemplar range e) ----
+        const int j0 = (int)((long)e * a.NB / a.c), j1 = (int)((long)(e + 1) * a.NB / a.c), nb = j1 - j0;
+        const int ft = g * W + w;
+        const bool on = ft < a.TT;                                // (wave-uniform) this wavefront has frames
+        const bool kl = a.mode == WIDE_KL;
+        if (nb > 0) stage_block(j0, 0);       // (the dictionary does not depend on anybody: its first block is on its way
+                                              // while the group's counter is polled)
+        if (it > 0 && !wait_for(a.rmode ? a.done_r + g : a.done + g, c * (unsigned)it)) break;
+
+        f32x4 Vin[MT], Vn[MT];
+#pragma unroll
+        for (int u = 0; u < MT; ++u) { Vin[u] = f32x4{0, 0, 0, 0}; Vn[u] = f32x4{0, 0, 0, 0}; }
+        bool live = false;
+        float h0v = 0.f;
+        if (on) {
+            const f32x4* xt = reinterpret_cast<const f32x4*>(a.Xw) + (size_t)ft * (MT * 64) + lane;
+            if (it == 0) {
+#pragma unroll
+                for (int u = 0; u < MT; ++u) Vin[u] = xt[u * 64];
+            } else if (a.rmode) {
+                const __amdgpu_buffer_rsrc_t rv =
+                    make_rsrc(a.Vsum + ((size_t)((par ^ 1u) * a.G + g) * W + w) * (TILE_B / 4), TILE_B);
+#pragma unroll
+                for (int u = 0; u < MT; ++u) Vin[u] = ld_sc1(rv, (u * 64 + lane) * 16u);
+            } else {
+                const __amdgpu_buffer_rsrc_t rv =
+                    make_rsrc(a.Vpart + ((size_t)((par ^ 1u) * a.G + g) * c) * W * (TILE_B / 4), c * W * TILE_B);
+                for (unsigned m = 0; m < c; ++m) {
+#pragma unroll
+                    for (int u = 0; u < MT; ++u) {
+                        const f32x4 v = ld_sc1(rv, (m * W + w) * TILE_B + (u * 64 + lane) * 16u);
+                        Vin[u] = m ? Vin[u] + v : v;
+                    }
+                }
+            }
+            if (kl && it > 0) {       // B operand of the KL numerator: X (/) max(V, eps)   (sklearn _nmf.py:560-575)
+#pragma unroll
+                for (int u = 0; u < MT; ++u) {
+                    const f32x4 x = xt[u * 64];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Vin[u][r] = x[r] / (Vin[u][r] < a.eps ? a.eps : Vin[u][r]);
+                }
+            }
+            const int t = ft * 16 + i16;
+            if (t < a.T_) {
+                const int ut = a.frame_utt[t];
+                if (ut >= 0) {
+                    live = a.active[ut] != 0;
+                    h0v = (float)a.h0[ut];
+                }
+            }
+        }
+        const __amdgpu_buffer_rsrc_t rh = make_rsrc(a.Hw + (size_t)(on ? ft : 0) * a.NB * 256, (unsigned)a.NB * 1024u);
+        const __amdgpu_buffer_rsrc_t rp = make_rsrc(a.Pw + (size_t)(on ? ft : 0) * a.NB * 256, (unsigned)a.NB * 1024u);
+        const bool load_h = it > 0 || !a.init_const, load_p = it > 0 && !kl;
+        // start value of the denominator's accumulator: l1, and pymf's + eps (ADD); iteration 0 forms the bare P
+        const float c0 = it == 0 ? 0.f : a.l1 + (a.mode == EVC_EPS_ADD ? a.eps : 0.f);
+        const int n_edge = (a.N & 15) ? a.NB - 1 : -1;           // the block that reaches into the zero padding
+        f32x4 hC = f32x4{0, 0, 0, 0}, pC = hC, hN = hC, pN = hC;
+        if (on && nb > 0) {
+            if (load_h) hC = ld_sc1(rh, (j0 * 64 + lane) * 16u);
+            if (load_p) pC = ld_sc1(rp, (j0 * 64 + lane) * 16u);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                          // block j0 is in stage 0
+
+        for (int i = 0; i < nb; ++i) {
+            const int jb = j0 + i;
+            const char* sb = smem + (i & 1) * IMG;
+            if (i + 1 < nb) {
+                stage_block(jb + 1, (i + 1) & 1);
+                if (on) {
+                    if (load_h) hN = ld_sc1(rh, ((jb + 1) * 64 + lane) * 16u);
+                    if (load_p) pN = ld_sc1(rp, ((jb + 1) * 64 + lane) * 16u);
+                }
+            }
+            if (on) {
+                // D = A_j^T Vin: two accumulation chains (a single wavefront per SIMD cannot issue dependent MFMAs back to back)
+                f32x4 d0 = f32x4{c0, c0, c0, c0}, d1 = f32x4{0, 0, 0, 0};
+                if (!(kl && it == 0)) {
+#pragma unroll
+                    for (int u = 0; u + 1 < MT; u += 2) {
+                        const f32x4 a0 = *reinterpret_cast<const f32x4*>(sb + (u * 64 + lane) * 16);
+                        const f32x4 a1 = *reinterpret_cast<const f32x4*>(sb + ((u + 1) * 64 + lane) * 16);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            d0 = Mma<float>::mma(a0[r], Vin[u][r], d0);
+                            d1 = Mma<float>::mma(a1[r], Vin[u + 1][r], d1);
+                        }
+                    }
+                    if (MT & 1) {
+                        const f32x4 a0 = *reinterpret_cast<const f32x4*>(sb + ((MT - 1) * 64 + lane) * 16);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) d0 = Mma<float>::mma(a0[r], Vin[MT - 1][r], d0);
+                    }
+                }
+                const f32x4 D = d0 + d1;
+                f32x4 hn;
+                if (it == 0) {
+                    // start values; P = A_j^T X goes to memory once
+                    if (a.init_const) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) hn[r] = (jb * 16 + 4 * q + r < a.N) ? h0v : 0.f;
+                        st_sc1(rh, (jb * 64 + lane) * 16u, hn);
+                    } else {
+                        hn = hC;
+                    }
+                    if (!kl) st_sc1(rp, (jb * 64 + lane) * 16u, D);
+                } else {
+                    switch (a.mode) {
+                        case EVC_EPS_ZERO_REPLACE:                       // sklearn _nmf.py:620-629
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) hn[r] = hC[r] * (pC[r] / (D[r] == 0.f ? a.eps : D[r]));
+                            break;
+                        case EVC_EPS_CLAMP:                              // deComP batch_mu.py
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) hn[r] = hC[r] * (pC[r] / (D[r] > a.eps ? D[r] : a.eps));
+                            break;
+                        case WIDE_KL:                                    // sklearn _nmf.py:556-606: H (.) (A/colsum)^T R
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) hn[r] = hC[r] * D[r];
+                            break;
+                        default:                                         // ADD (eps already in D), NONE: (h p) / d
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) hn[r] = (hC[r] * pC[r]) / D[r];
+                            break;
+                    }
+                    if (jb == n_edge) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) hn[r] = (jb * 16 + 4 * q + r < a.N) ? hn[r] : 0.f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hn[r] = live ? hn[r] : hC[r];     // frozen (stopped utterance) / padding
+                    st_sc1(rh, (jb * 64 + lane) * 16u, hn);
+                }
+                // V' += A_j H'_j: neighbouring accumulators alternate
+                const char* s2 = sb + MT * 1024;
+#pragma unroll
+                for (int u = 0; u + 1 < MT; u += 2) {
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(s2 + (u * 64 + lane) * 16);
+                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(s2 + ((u + 1) * 64 + lane) * 16);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        Vn[u] = Mma<float>::mma(a0[r], hn[r], Vn[u]);
+                        Vn[u + 1] = Mma<float>::mma(a1[r], hn[r], Vn[u + 1]);
+                    }
+                }
+                if (MT & 1) {
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(s2 + ((MT - 1) * 64 + lane) * 16);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Vn[MT - 1] = Mma<float>::mma(a0[r], hn[r], Vn[MT - 1]);
+                }
+            }
+            __syncthreads();            // (waits vmcnt(0): the next block has landed; everybody is done with this stage)
+            hC = hN;
+            pC = pN;
+        }
+
+        // publish the partial V' of this range
+        if (on) {
+            const __amdgpu_buffer_rsrc_t rv =
+                make_rsrc(a.Vpart + (((size_t)(par * a.G + g) * c + e) * W + w) * (TILE_B / 4), TILE_B);
+#pragma unroll
+            for (int u = 0; u < MT; ++u) st_sc1(rv, (u * 64 + lane) * 16u, Vn[u]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_fetch_add(a.done + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_ctl[0] = nxt;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// packing / unpacking (once per call; once per dictionary when it was prepared)
+// ------------------------------------------------------------------------------------------
+// Aw[jb][0][u][lane = 16 q + i][r]  = A1[bin 16 u + 4 q + r][exemplar 16 jb + i]      (A operand of D; A1 = A, or A / colsum for KL)
+// Aw[jb][1][u][lane = 16 q + i][r]  = A [bin 16 u + i][exemplar 16 jb + 4 q + r]      (A operand of V')
+// At1 / At2: exemplars as rows (n_rows x ld, zero padded), bins < ld
+__global__ __launch_bounds__(256) void k_wide_pack_dict(const float* __restrict__ At1, const float* __restrict__ At2,
+                                                        int ld, int n_rows, int NB, int MT, float* __restrict__ Aw) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long per_block = 2L * MT * 256;
+    if (gid >= (long)NB * per_block) return;
+    const long jb = gid / per_block;
+    const int o = (int)(gid - jb * per_block);
+    const int half = o / (MT * 256), o2 = o - half * MT * 256;
+    const int u = o2 >> 8, lane = (o2 >> 2) & 63, r = o2 & 3, q = lane >> 4, i = lane & 15;
+    const int bin = half ? 16 * u + i : 16 * u + 4 * q + r;
+    const long n = half ? 16 * jb + 4 * q + r : 16 * jb + i;
+    const float* src = half ? At2 : At1;
+    Aw[gid] = (n < n_rows && bin < ld) ? src[n * ld + bin] : 0.f;
+}
+
+// Xw[ft][u][lane = 16 q + i][r] = X[frame 16 ft + i][bin 16 u + 4 q + r]      (Xt: frames as rows, rows x ld, zero padded)
+__global__ __launch_bounds__(256) void k_wide_pack_x(const float* __restrict__ Xt, int ld, int rows, long tiles, int MT,
+                                                     float* __restrict__ Xw) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= tiles * MT * 256) return;
+    const long ft = gid / (MT * 256);
+    const int o = (int)(gid - ft * MT * 256);
+    const int u = o >> 8, lane = (o >> 2) & 63, r = o & 3, q = lane >> 4, i = lane & 15;
+    const long t = 16 * ft + i;
+    const int bin = 16 * u + 4 * q + r;
+    Xw[gid] = (t < rows && bin < ld) ? Xt[t * ld + bin] : 0.f;
+}
+
+// Hw[ft][jb][lane = 16 q + i][r] <-> H[exemplar 16 jb + 4 q + r][frame 16 ft + i] of the caller (frame_major: H[t ldh + n],
+// else H[n ldh + t]).  Import: zero outside; export: NaN everywhere when the solve was aborted.
+template <bool IMPORT>
+__global__ __launch_bounds__(256) void k_wide_h_io(float* __restrict__ H, long ldh, int frame_major, int T_, int N,
+                                                   f32x4* __restrict__ Hw, long tiles, int NB, int NBw, const int* abort) {
+    const int lane = threadIdx.x & 63;
+    const long tile = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= tiles) return;
+    const long ft = tile / NB, jb = tile % NB;
+    const int q = lane >> 4, i = lane & 15;
+    const long t = 16 * ft + i, n0 = 16 * jb + 4 * q;
+    f32x4* hw = Hw + (ft * NBw + jb) * 64 + lane;
+    if (IMPORT) {
+        f32x4 v = f32x4{0, 0, 0, 0};
+        if (t < T_) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n0 + r < N) v[r] = frame_major ? H[t * ldh + n0 + r] : H[(n0 + r) * ldh + t];
+        }
+        *hw = v;
+    } else {
+        if (t >= T_) return;
+        f32x4 v = *hw;
+        if (abort && *abort) v = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+        if (frame_major && n0 + 3 < N && ((reinterpret_cast<uintptr_t>(H + t * ldh + n0) & 15) == 0)) {
+            *reinterpret_cast<f32x4*>(H + t * ldh + n0) = v;
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n0 + r < N) {
+                    if (frame_major) H[t * ldh + n0 + r] = v[r]; else H[(n0 + r) * ldh + t] = v[r];
+                }
+        }
+    }
+}
+
+// err2[t] = sum_m (X - V)^2 of frame t, or 2 KL(X || V) (see k_frame_err_kl), V = the sum of the c partials of
+// iteration `it` (or their reduced sum); one wavefront per frame tile
+__global__ __launch_bounds__(256) void k_wide_err2(WideArgs a, int MT, int W, int it, double eps, int kl,
+                                                   double* __restrict__ err2) {
+    const int lane = threadIdx.x & 63;
+    const long ft = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ft >= a.TT) return;
+    const int g = (int)(ft / W), w = (int)(ft % W);
+    const unsigned par = (unsigned)(it & 1);
+    const size_t tile = (size_t)MT * 64;          // float4 per tile
+    const f32x4* xt = reinterpret_cast<const f32x4*>(a.Xw) + (size_t)ft * tile + lane;
+    double acc = 0.0;
+    for (int u = 0; u < MT; ++u) {
+        f32x4 v;
+        if (a.rmode) {
+            v = (reinterpret_cast<const f32x4*>(a.Vsum) + ((size_t)(par * a.G + g) * W + w) * tile)[u * 64 + lane];
+        } else {
+            const f32x4* p = reinterpret_cast<const f32x4*>(a.Vpart) + ((size_t)(par * a.G + g) * a.c * W + w) * tile;
+            v = p[u * 64 + lane];
+            for (int m = 1; m < a.c; ++m) v += p[(size_t)m * W * tile + u * 64 + lane];
+        }
+        const f32x4 x = xt[u * 64];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double xd = x[r], vd = v[r];
+            if (kl) {
+                acc += vd;
+                if (xd > eps) acc += xd * log(xd / (vd < eps ? eps : vd)) - xd;
+            } else {
+                acc += (xd - vd) * (xd - vd);
+            }
+        }
+    }
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
+    const long t = 16 * ft + (lane & 15);
+    if (lane < 16 && t < a.T_) err2[t] = kl ? 2.0 * acc : acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static const int WIDE_MT_SET[] = {4, 6, 8, 10, 13};
+
+size_t wide_ctl_words(const WideLayout& f) { return 4 + 2 * (size_t)f.G; }
+
+bool wide_supported(int M, int N, int T_, int dtype, int algo) {
+    return dtype == EVC_F32 && algo == EVC_ALGO_FACTORED && M > 32 && M <= 208 && N >= 16 && T_ >= 1;
+}
+
+WideLayout wide_layout(int M, int N, int T_, int n_cus, int c_req, int w_req) {
+    WideLayout f{};
+    const int mt = (M + 15) / 16;
+    f.MT = 13;
+    for (int v : WIDE_MT_SET)
+        if (v >= mt) { f.MT = v; break; }
+    f.NB = (N + 15) / 16;
+    f.TT = (T_ + 15) / 16;
+    if (n_cus <= 0) n_cus = 256;
+    // 8 wavefronts per workgroup (two per SIMD cover each other's latencies; half the dictionary traffic per flop)
+    // once there are frame tiles for it; 4 for a few utterances, where more, smaller groups keep the partial sums small
+    f.W = w_req == 4 || w_req == 8 ? w_req : (f.TT >= 2 * n_cus ? 8 : 4);
+    f.G = (f.TT + f.W - 1) / f.W;
+    // ranges per frame group: enough tasks per iteration to keep every CU busy (none when the groups alone do)
+    int c = c_req > 0 ? c_req : (f.G >= n_cus ? 1 : (n_cus + f.G - 1) / f.G);
+    const int cmax = f.NB / 2 > 0 ? f.NB / 2 : 1;
+    if (c > cmax) c = cmax;
+    if (c > 64) c = 64;
+    f.c = c;
+    f.rmode = c > 4 ? 1 : 0;
+    const size_t tile = (size_t)f.MT * 256;      // floats per V tile
+    f.aw = (size_t)f.NB * 2 * tile;
+    f.xw = (size_t)f.G * f.W * tile;
+    f.hw = (size_t)f.G * f.W * f.NB * 256;
+    f.vpart = 2 * (size_t)f.G * f.c * f.W * tile;
+    f.vsum = 2 * (size_t)f.G * f.W * tile;
+    return f;
+}
+
+// element counts the workspace must provide so that the automatic layout AND the tuning overrides (wavefronts per
+// workgroup 4 / 8, up to 8 ranges for small batches) fit
+WideCaps wide_caps(int M, int N, int T_, int n_cus) {
+    const WideLayout a4 = wide_layout(M, N, T_, n_cus, 0, 4), a8 = wide_layout(M, N, T_, n_cus, 0, 8);
+    WideCaps k{};
+    const size_t tile = (size_t)a4.MT * 256, ttp = (size_t)round_up(a4.TT, 8);
+    int c_cap = a4.c > a8.c ? a4.c : a8.c;
+    if (a4.TT <= 4096 && c_cap < 8) c_cap = 8;
+    k.c_cap = c_cap;
+    k.aw = a4.aw;
+    k.xw = ttp * tile;
+    k.hw = ttp * a4.NB * 256;
+    k.vpart = 2 * ttp * c_cap * tile;
+    k.vsum = 2 * ttp * tile;
+    k.ctl = 4 + 2 * (size_t)((a4.TT + 3) / 4);
+    return k;
+}
+bool wide_fits(const WideLayout& f, const WideCaps& k) {
+    return f.aw <= k.aw && f.xw <= k.xw && f.hw <= k.hw && f.vpart <= k.vpart && f.vsum <= k.vsum &&
+           wide_ctl_words(f) <= k.ctl;
+}
+
+hipError_t wide_pack_dict(const WideLayout& f, const float* At1, const float* At2, int ld, int n_rows, float* Aw,
+                          hipStream_t s) {
+    const long n = (long)f.aw;
+    hipLaunchKernelGGL(k_wide_pack_dict, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, At1, At2, ld, n_rows, f.NB,
+                       f.MT, Aw);
+    return hipGetLastError();
+}
+
+hipError_t wide_pack_x(const WideLayout& f, const float* Xt, int ld, int rows, float* Xw, hipStream_t s) {
+    const long tiles = (long)f.G * f.W, n = tiles * f.MT * 256;
+    hipLaunchKernelGGL(k_wide_pack_x, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Xt, ld, rows, tiles, f.MT, Xw);
+    return hipGetLastError();
+}
+
+hipError_t wide_import_h(const WideLayout& f, float* Hw, const float* H, long ldh, int frame_major, int T_, int N,
+                         hipStream_t s) {
+    const long tiles = (long)f.G * f.W * f.NB;
+    hipLaunchKernelGGL((k_wide_h_io<true>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, const_cast<float*>(H), ldh,
+                       frame_major, T_, N, reinterpret_cast<f32x4*>(Hw), tiles, f.NB, f.NB, (const int*)nullptr);
+    return hipGetLastError();
+}
+
+hipError_t wide_export_h(const WideLayout& f, const float* Hw, float* H, long ldh, int frame_major, int T_, int N,
+                         const int* abort, hipStream_t s) {
+    const long tiles = (long)f.TT * f.NB;
+    hipLaunchKernelGGL((k_wide_h_io<false>), dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, s, H, ldh, frame_major, T_, N,
+                       reinterpret_cast<f32x4*>(const_cast<float*>(Hw)), tiles, f.NB, f.NB, abort);
+    return hipGetLastError();
+}
+
+static WideArgs wide_args(const WideLayout& f, const WideBuffers& b, const UttState& u, int N, int T_, int mode,
+                          double eps, double l1, int init_const) {
+    WideArgs a{};
+    a.Aw = b.Aw; a.Xw = b.Xw; a.Hw = b.Hw; a.Pw = b.Pw; a.Vpart = b.Vpart; a.Vsum = b.Vsum;
+    a.ticket = b.ctl; a.done = b.ctl + 4; a.done_r = b.ctl + 4 + f.G; a.abort = reinterpret_cast<int*>(b.ctl + 1);
+    a.frame_utt = u.frame_utt; a.active = u.active; a.h0 = u.h0;
+    a.NB = f.NB; a.TT = f.TT; a.G = f.G; a.c = f.c; a.rmode = f.rmode;
+    a.N = N; a.T_ = T_; a.mode = mode; a.eps = (float)eps; a.l1 = (float)l1; a.init_const = init_const;
+    return a;
+}
+
+
+// zero the task counters and the abort flag: once per solve, before the first wide_iterate
+hipError_t wide_begin(const WideLayout& f, const WideBuffers& b, hipStream_t s) {
+    return hipMemsetAsync(b.ctl, 0, wide_ctl_words(f) * sizeof(unsigned), s);
+}
+
+template <int MT, int W>
+static hipError_t wide_launch(const WideArgs& a, unsigned grid, hipStream_t s) {
+    const size_t lds = 2 * (size_t)(2 * MT * 1024) + 16;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_wide<MT, W>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_fused_wide<MT, W>), dim3(grid), dim3(W * 64), lds, s, a);
+    return hipGetLastError();
+}
+
+template <int W>
+static hipError_t wide_dispatch(int MT, const WideArgs& a, unsigned grid, hipStream_t s) {
+    switch (MT) {
+        case 4: return wide_launch<4, W>(a, grid, s);
+        case 6: return wide_launch<6, W>(a, grid, s);
+        case 8: return wide_launch<8, W>(a, grid, s);
+        case 10: return wide_launch<10, W>(a, grid, s);
+        case 13: return wide_launch<13, W>(a, grid, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// iterations [it_begin, it_end) in one launch (iteration 0: P = A^T X and V = A H0); one workgroup per CU
+hipError_t wide_iterate(const WideLayout& f, const WideBuffers& b, const UttState& u, int N, int T_, int it_begin,
+                        int it_end, int mode, double eps, double l1, int init_const, int n_cus, hipStream_t s) {
+    if (it_end <= it_begin) return hipSuccess;
+    WideArgs a = wide_args(f, b, u, N, T_, mode, eps, l1, init_const);
+    a.it_begin = it_begin; a.it_end = it_end;
+    hipError_t e = hipMemsetAsync(b.ctl, 0, sizeof(unsigned), s);       // the ticket counter of this launch
+    if (e != hipSuccess) return e;
+    const long per_it = (long)f.G * f.c * (f.rmode ? 2 : 1);
+    const long tasks = per_it * (it_end - it_begin);
+    if (n_cus <= 0) n_cus = 256;
+    const unsigned grid = (unsigned)(tasks < n_cus ? tasks : n_cus);
+    return f.W == 8 ? wide_dispatch<8>(f.MT, a, grid, s) : wide_dispatch<4>(f.MT, a, grid, s);
+}
+
+// per-frame residuals of the activations after iteration `it` (the V' that iteration published)
+hipError_t wide_err2(const WideLayout& f, const WideBuffers& b, const UttState& u, int N, int T_, int it, int kl,
+                     double eps, double* err2, hipStream_t s) {
+    WideArgs a = wide_args(f, b, u, N, T_, 0, eps, 0.0, 0);
+    hipLaunchKernelGGL(k_wide_err2, dim3((unsigned)((f.TT + 3) / 4)), dim3(256), 0, s, a, f.MT, f.W, it, eps, kl, err2);
+    return hipGetLastError();
+}
+
+}  // namespace evc

@@ -1,0 +1,146 @@
+"""k_fused_wide (evc_wide.hip): the fused FACTORED update for wide float32 spectra (32 < M <= 208 bins) - the
+|Re STFT| stream the reference script runs by default (04_align_n_nmf.py:315-326, config/config:12).
+
+Every case enters through the C ABI (evc_nmf_solve / evc_nmf_convert) and is compared with the float64 oracle run
+on the same float32 inputs.  Tolerance: float32 trajectories of different summation orders drift apart at about
+K sqrt(N) 6e-8, hence rtol 2e-3 with an absolute floor of 1e-6 max|H| (north_star asks 1e-4 of the float64 path).
+The exemplar ranges per frame group (c) and the wavefronts per workgroup (W) are forced through the tuning bits so
+that every dependency pattern of the task queue runs: no split, the direct sum of 2-4 partials, the reduce tasks."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, load_golden  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+RTOL, AFLOOR = 2e-3, 1e-6
+
+
+def oracle():
+    from oracle import evc_oracle as o
+    return o
+
+
+def check(got, want, rtol=RTOL):
+    want = np.asarray(want, dtype=np.float64)
+    np.testing.assert_allclose(np.asarray(got, dtype=np.float64), want, rtol=rtol, atol=AFLOOR * float(np.abs(want).max()))
+
+
+def sk_want(o, A32, X32, K, l1=0.0):
+    """the scikit-learn update in float64 on the float32 inputs (bins as rows)"""
+    N = A32.shape[1]
+    X64 = X32.astype(np.float64)
+    return o.mu_solve(A32.astype(np.float64), X64, np.full((N, X32.shape[1]), np.sqrt(X64.mean() / N)), K,
+                      eps_mode=o.EPS_ZERO_REPLACE, eps=float(np.finfo(np.float32).eps), l1=l1, algo="factored")
+
+
+@pytest.mark.parametrize("M,N,T,K,c,w", [
+    (201, 256, 64, 20, 0, 0), (201, 256, 64, 20, 1, 4), (201, 256, 64, 20, 2, 8), (201, 250, 50, 20, 3, 4),
+    (201, 1000, 688, 30, 0, 0), (201, 1000, 688, 30, 6, 4), (201, 1000, 100, 30, 8, 8), (201, 1000, 100, 30, 4, 8),
+    (33, 300, 100, 25, 0, 0), (64, 512, 130, 25, 4, 0), (100, 512, 130, 25, 5, 0), (150, 200, 33, 25, 0, 8),
+    (208, 4096, 688, 20, 0, 0), (201, 17, 5, 10, 0, 0), (201, 4096, 1, 15, 0, 0),
+])
+def test_wide_kernel_against_the_oracle(M, N, T, K, c, w):
+    import exemplars_vc_amd as evc
+    o = oracle()
+    p = o.synth_problem(M, N, T, seed=M + N + T)
+    A32, X32 = p["A"].astype(np.float32), p["X"].astype(np.float32)
+    got, info = evc.solve_activations(A32, X32, iters=K, eps_mode="zero_replace", init="sklearn", fused_c=c, fused_w=w,
+                                      info=True)
+    assert info["kernel"] == "k_fused_wide" and info["launches"] == 1 and info["redo"] == 0, info
+    if c:
+        assert info["members"] == min(c, max(1, ((N + 15) // 16) // 2)), info
+    assert got.dtype == np.float32
+    check(got, sk_want(o, A32, X32, K))
+
+
+@pytest.mark.parametrize("layout", ["bin_major", "frame_major"])
+@pytest.mark.parametrize("eps_mode,eps", [("add", 1e-9), ("none", 0.0), ("clamp", 1e-15)])
+def test_wide_other_surfaces_and_convert(layout, eps_mode, eps):
+    """pymf / nmf_tool / deComP guards with a given start, both orientations, H and Y = B H from one call"""
+    import exemplars_vc_amd as evc
+    o = oracle()
+    p = o.synth_problem(201, 500, 90, seed=4)
+    A32, X32, B32 = (p[k].astype(np.float32) for k in ("A", "X", "B"))
+    H0 = (np.random.default_rng(0).random((500, 90)) + 1e-4).astype(np.float32)
+    want = o.mu_solve(A32.astype(np.float64), X32.astype(np.float64), H0.astype(np.float64), 30,
+                      eps_mode={"add": o.EPS_ADD, "none": o.EPS_NONE, "clamp": o.EPS_CLAMP}[eps_mode], eps=eps,
+                      algo="factored")
+    tr = (lambda z: z) if layout == "bin_major" else (lambda z: np.ascontiguousarray(z.T))
+    H, Y, info = evc.convert(tr(A32), tr(X32), tr(B32), tr(H0), layout=layout, iters=30, eps_mode=eps_mode, eps=eps,
+                             info=True)
+    assert info["kernel"] == "k_fused_wide"
+    H, Y = (H, Y) if layout == "bin_major" else (H.T, Y.T)
+    check(H, want)
+    check(Y, B32.astype(np.float64) @ want)
+
+
+def test_wide_l1_and_the_stop_rule_per_utterance():
+    """the scikit-learn call of 04_align_n_nmf.py:212 on float32 rows: tol = 1e-3 stop test every 10 iterations, three
+    utterances in one batch, each with its own start value, error trace and n_iter; then the L1 variant"""
+    import exemplars_vc_amd as evc
+    o = oracle()
+    p = o.synth_problem(201, 512, 230, seed=9)
+    X_rows = np.ascontiguousarray(p["X"].T).astype(np.float32)
+    W_rows = np.ascontiguousarray(p["A"].T).astype(np.float32)
+    offs = [0, 100, 130, 230]
+    H, info = evc.solve_activations(W_rows, X_rows, layout="frame_major", iters=150, eps_mode="zero_replace",
+                                    init="sklearn", check_every=10, stop_rule="sklearn", tol=1e-3, utt_offsets=offs,
+                                    info=True)
+    assert info["kernel"] == "k_fused_wide" and info["launches"] >= 2
+    for u in range(3):
+        a, b = offs[u], offs[u + 1]
+        act, n_ref, _ = o.sklearn_mu_fixed_dictionary(X_rows[a:b].astype(np.float64), W_rows.astype(np.float64), 150, 1e-3)
+        assert int(info["n_iter"][u]) == n_ref, (u, info["n_iter"], n_ref)
+        check(H[a:b], act, rtol=5e-3)
+    act, _, _ = o.sklearn_mu_fixed_dictionary(X_rows.astype(np.float64), W_rows.astype(np.float64), 40, 0.0, l1_reg=2.01)
+    Hl = evc.solve_activations(W_rows, X_rows, layout="frame_major", iters=40, eps_mode="zero_replace", init="sklearn",
+                               l1=2.01)
+    check(Hl, act)
+
+
+def test_wide_kl():
+    import exemplars_vc_amd as evc
+    o = oracle()
+    p = o.synth_problem(201, 384, 70, seed=2)
+    X_rows = np.ascontiguousarray(p["X"].T).astype(np.float32)
+    W_rows = np.ascontiguousarray(p["A"].T).astype(np.float32)
+    act, _, _ = o.sklearn_mu_fixed_dictionary_kl(X_rows.astype(np.float64), W_rows.astype(np.float64), 40, 0.0)
+    for c in (0, 3, 6):
+        Hk, info = evc.solve_activations(W_rows, X_rows, layout="frame_major", iters=40, eps_mode="zero_replace",
+                                         init="sklearn", loss="kl", fused_c=c, info=True)
+        assert info["kernel"] == "k_fused_wide"
+        check(Hk, act, rtol=5e-3)
+
+
+def test_wide_repeatable_and_independent_of_the_batch():
+    """the partial sums are combined in range order: two runs agree bitwise; an utterance inside a batch equals the
+    same utterance alone when both use the same number of ranges (same summation order)"""
+    import exemplars_vc_amd as evc
+    o = oracle()
+    p = o.synth_problem(201, 1024, 300, seed=12)
+    A32, X32 = p["A"].astype(np.float32), p["X"].astype(np.float32)
+    kw = dict(iters=25, eps_mode="zero_replace", init="sklearn", fused_c=5, fused_w=4)
+    a = evc.solve_activations(A32, X32, utt_offsets=[0, 120, 300], **kw)
+    b = evc.solve_activations(A32, X32, utt_offsets=[0, 120, 300], **kw)
+    assert np.array_equal(a, b)
+    lone = evc.solve_activations(A32, X32[:, 128:300], iters=25, eps_mode="zero_replace", init="const",
+                                 init_value=float(np.sqrt(X32[:, 120:300].astype(np.float64).mean() / 1024)), fused_c=5,
+                                 fused_w=4)
+    # frames 128.. of the batch sit in whole tiles of utterance 2 and start from the same constant
+    np.testing.assert_allclose(a[:, 128:300], lone, rtol=1e-6, atol=0)
+
+
+def test_wide_real_audio_golden():
+    """the |Re STFT| fixture made from the reference's own audio with the installed scikit-learn (tools/make_golden.py)"""
+    import exemplars_vc_amd as evc
+    from exemplars_vc_amd.compat.factorize import _factorize
+    import warnings
+    g = load_golden(GOLDEN + "/sklearn_audio_stft.npz")
+    X, W = g["X_rows"].astype(np.float32), g["W_rows"].astype(np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        H = _factorize(X, W, tol=float(g["tol"]))
+    assert H.dtype == np.float32 and H.shape == g["H"].shape
+    # (the float32 trajectory may stop one check later or earlier than the float64 one: compare with the float64
+    # oracle run on the float32 inputs to the iteration count the device reports when they differ)
+    check(H, g["H"], rtol=2e-2)
