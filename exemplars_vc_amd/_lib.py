@@ -26,7 +26,7 @@ SYMBOLS = ("evc_version", "evc_strerror", "evc_device_count", "evc_workspace_byt
            "evc_nmf_solve", "evc_nmf_convert", "evc_synthesize", "evc_residual",
            "evc_griffin_lim_workspace_bytes", "evc_griffin_lim", "evc_griffin_lim_batch_workspace_bytes",
            "evc_griffin_lim_batch", "evc_dtw_workspace_bytes", "evc_dtw_align",
-           "evc_stft_frames", "evc_stft_workspace_bytes", "evc_stft")
+           "evc_stft_frames", "evc_stft_workspace_bytes", "evc_stft", "evc_dict_bytes", "evc_dict_prepare")
 
 
 class SolveOpts(C.Structure):
@@ -37,7 +37,16 @@ class SolveOpts(C.Structure):
         ("check_every", C.c_int), ("stop_rule", C.c_int), ("reserved", C.c_int),
         ("loss", C.c_int), ("test_abort_at", C.c_int),
         ("eps", C.c_double), ("l1", C.c_double), ("tol", C.c_double), ("init_value", C.c_double),
-        ("ev_loop_start", C.c_void_p), ("ev_loop_stop", C.c_void_p), ("info", C.c_void_p),
+        ("ev_loop_start", C.c_void_p), ("ev_loop_stop", C.c_void_p), ("info", C.c_void_p), ("dict", C.c_void_p),
+    ]
+
+
+class Dict(C.Structure):
+    """Mirror of `evc_dict` (include/evc.h): a dictionary imported once (evc_dict_prepare)."""
+    _fields_ = [
+        ("struct_bytes", C.c_int), ("magic", C.c_int), ("M", C.c_int), ("Mb", C.c_int), ("N", C.c_int),
+        ("dtype", C.c_int), ("loss", C.c_int), ("reserved", C.c_int),
+        ("eps", C.c_double), ("mem", C.c_void_p), ("bytes", C.c_size_t),
     ]
 
 
@@ -100,6 +109,11 @@ def lib():
         C.POINTER(C.c_int), C.c_int, C.POINTER(SolveOpts),
         C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_void_p,
     ]
+    L.evc_dict_bytes.restype = C.c_size_t
+    L.evc_dict_bytes.argtypes = [C.c_int] * 5
+    L.evc_dict_prepare.restype = C.c_int
+    L.evc_dict_prepare.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.c_int, C.c_double, C.c_void_p, C.c_size_t, C.POINTER(Dict), C.c_void_p]
     L.evc_synthesize.restype = C.c_int
     L.evc_synthesize.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                  C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]

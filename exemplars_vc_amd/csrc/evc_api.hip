@@ -47,6 +47,56 @@ Dims make_dims(int esize, int M, int N, int T_, int n_utt, int Mb = 0) {
     return d;
 }
 
+constexpr int DICT_MAGIC = 0x45564344;      // "EVCD"
+
+// What a solve needs of the dictionary, whatever the frames are.  Carved from the call's workspace and filled on every
+// call, or - with a prepared dictionary (evc_dict_prepare) - carved from its image, filled once.
+struct DictPlan {
+    bool fused;          // float64 fused kernels (M <= 32): operand fragments, row sums
+    bool packed_b;       // ... and B's fragments for the synthesis from packed tiles (1 <= Mb <= 32)
+    bool wide;           // k_fused_wide's block images (float32, 32 < M <= 208)
+    bool kl;             // the dictionary divided by its column sums
+    bool bc;             // a compact exemplars-as-rows copy of B (prepared images: the caller's B is not consulted)
+};
+template <typename T> struct DictArrays {
+    T *At, *Am, *Akl;
+    double *A1p, *A2p, *rsum;
+    T* Bt;
+    double *B1p, *B2p;
+    T* Bc;
+    float* Aw;
+};
+template <typename T> DictPlan dict_plan(int M, int Mb, int N, int loss, bool prepared) {
+    DictPlan p{};
+    p.kl = loss == EVC_LOSS_KL;
+    p.fused = sizeof(T) == 8 && fused_supported(M, N, 1, EVC_F64);
+    p.packed_b = p.fused && Mb >= 1 && Mb <= 32;
+    p.wide = sizeof(T) == 4 && wide_supported(M, N, 1, EVC_F32, EVC_ALGO_FACTORED);
+    p.bc = prepared && Mb >= 1;
+    return p;
+}
+template <typename T> DictArrays<T> take_dict(Carver& c, const Dims& d, const DictPlan& p) {
+    DictArrays<T> a{};
+    a.At = c.take<T>((size_t)d.Np * d.Mk);
+    a.Am = c.take<T>((size_t)d.Mj * d.Np);
+    a.Akl = c.take<T>((size_t)d.Np * d.Mk);
+    if (p.fused) {
+        const FusedLayout fl = fused_layout(d.M, d.N, 1);
+        a.A1p = c.take<double>(fl.a1);
+        a.A2p = c.take<double>(fl.a2);
+        a.rsum = c.take<double>(32);
+    }
+    if (p.packed_b) {
+        const FusedLayout flB = fused_layout(d.Mb, d.N, 1);
+        a.Bt = c.take<T>((size_t)d.Np * 32);
+        a.B1p = c.take<double>(flB.a1);
+        a.B2p = c.take<double>(flB.a2);
+    }
+    if (p.wide) a.Aw = c.take<float>(wide_layout(d.M, d.N, 1, 256, 0, 0).aw);
+    if (p.bc) a.Bc = c.take<T>((size_t)d.N * d.Mb);
+    return a;
+}
+
 template <typename T> struct Workspace {
     T *At, *Am, *Xt, *H0, *H1, *Pt, *G, *Vt;
     T *Akl, *Rt;         // KL: dictionary / column sums, and X / max(V, eps)
@@ -67,15 +117,21 @@ template <typename T> struct Workspace {
 int n_slots_for(int iters, int check_every) { return 1 + (check_every > 0 ? iters / check_every : 0); }
 
 template <typename T>
-Workspace<T> carve(void* base, const Dims& d, int algo, int n_slots, bool fused) {
+Workspace<T> carve(void* base, const Dims& d, int algo, int n_slots, bool fused, const DictArrays<T>* ext = nullptr) {
     Workspace<T> w;
     Carver c{static_cast<char*>(base), 0};
     const bool gram = (algo == EVC_ALGO_GRAM || algo == EVC_ALGO_LITERAL);
     w.fused = fused;
-    w.At = c.take<T>((size_t)d.Np * d.Mk);
-    w.Am = c.take<T>((size_t)d.Mj * d.Np);
+    // the dictionary's arrays: from the prepared image, or from this workspace (then filled on every call)
+    DictPlan plan = dict_plan<T>(d.M, d.Mb, d.N, EVC_LOSS_KL, false);
+    plan.fused = fused;
+    plan.packed_b = fused && d.Mb >= 1 && d.Mb <= 32;
+    plan.wide = false;
+    const DictArrays<T> da = ext ? *ext : take_dict<T>(c, d, plan);
+    w.At = da.At;
+    w.Am = da.Am;
+    w.Akl = da.Akl;
     w.Xt = c.take<T>((size_t)d.Tp * d.Mk);
-    w.Akl = c.take<T>((size_t)d.Np * d.Mk);
     w.Rt = fused ? nullptr : c.take<T>((size_t)d.Tp * d.Mk);
     w.packed_synth = fused && d.Mb >= 1 && d.Mb <= 32;
     // the fused path keeps the activations in the packed layout only; a frames-as-rows copy is
@@ -93,24 +149,25 @@ Workspace<T> carve(void* base, const Dims& d, int algo, int n_slots, bool fused)
     w.fb = FusedBuffers{};
     if (fused) {
         w.fl = fused_layout(d.M, d.N, d.T_);
-        w.fb.A1p = c.take<double>(w.fl.a1);
-        w.fb.A2p = c.take<double>(w.fl.a2);
+        w.fb.A1p = da.A1p;
+        w.fb.A2p = da.A2p;
         w.fb.Xp = c.take<double>(w.fl.xp);
         w.fb.Hp = c.take<double>(w.fl.hp);
         w.fb.Vp = c.take<double>(w.fl.vp);
         static_assert(ALL_MAX_WGS >= COOP_MAX_TILES, "coop_buf is sized by k_fused_all's layout");
         w.fb.coop_buf = c.take<double>((size_t)(ALL_SLICE_OFFSET + ALL_SLICE_ELEMS));
         w.fb.coop_cnt = c.take<int>(COOP_MAX_TILES + 1);
-        w.fb.rsum = c.take<double>(32);
+        w.fb.rsum = da.rsum;
         w.fb.coop_c = 1;
     }
     w.flB = FusedLayout{};
     w.Bt = nullptr; w.B1p = w.B2p = w.Yp = nullptr;
     if (w.packed_synth) {
         w.flB = fused_layout(d.Mb, d.N, d.T_);
-        w.Bt = c.take<T>((size_t)d.Np * 32);
-        w.B1p = c.take<double>(w.flB.a1);
-        w.B2p = c.take<double>(w.flB.a2);
+        // (a prepared dictionary without B: these come from the workspace and are filled per call)
+        w.Bt = da.Bt ? da.Bt : c.take<T>((size_t)d.Np * 32);
+        w.B1p = da.B1p ? da.B1p : c.take<double>(w.flB.a1);
+        w.B2p = da.B2p ? da.B2p : c.take<double>(w.flB.a2);
         w.Yp = c.take<double>(w.flB.vp);
     }
     w.H1 = gram ? c.take<T>((size_t)d.Tp * d.Np) : nullptr;
@@ -145,6 +202,8 @@ constexpr int MAX_SLOTS = 4097;
 
 struct SynthArgs {          // optional Y = B H appended to a solve (evc_nmf_convert)
     const void* B; int ldb; void* Y; int ldy; int Mb;
+    int b_rows;             // 1: B is exemplars-as-rows whatever the call's layout (a prepared dictionary's copy)
+    int b_packed;           // 1: B's fragments are already in the dictionary image (nothing to import)
 };
 
 // hand back the per-utterance results
@@ -165,10 +224,82 @@ template <typename T>
 int synth_rows(const T* Hc, long ldc, const SynthArgs& y, int N, int T_, bool fm, hipStream_t s) {
     const T* B = static_cast<const T*>(y.B);
     T* Y = static_cast<T*>(y.Y);
+    // B(n, mb) = B[n bsn + mb bsm]
+    const long bsn = (fm || y.b_rows) ? y.ldb : 1, bsm = (fm || y.b_rows) ? 1 : y.ldb;
     if (fm)   // Y[t][mb] = sum_n Hc[t][n] B[n][mb]
-        HIP_TRY(gemm_strided<T>(Hc, ldc, 1, B, 1, y.ldb, Y, y.ldy, 1, T_, y.Mb, N, s));
+        HIP_TRY(gemm_strided<T>(Hc, ldc, 1, B, bsm, bsn, Y, y.ldy, 1, T_, y.Mb, N, s));
     else      // Y[mb][t] = sum_n B[mb][n] Hc[t][n]
-        HIP_TRY(gemm_strided<T>(B, y.ldb, 1, Hc, ldc, 1, Y, y.ldy, 1, y.Mb, T_, N, s));
+        HIP_TRY(gemm_strided<T>(B, bsm, bsn, Hc, ldc, 1, Y, y.ldy, 1, y.Mb, T_, N, s));
+    return ST_OK;
+}
+
+// Bring the caller's dictionary into the arrays of `a` (every layout the plan names).  B may be NULL.
+template <typename T>
+int prepare_dict(const DictArrays<T>& a, const DictPlan& p, const T* A, int lda, const T* B, int ldb, const Dims& d,
+                 bool fm, double eps, bool want_rowsum, hipStream_t s) {
+    HIP_TRY(copy2d<T>(A, lda, d.N, d.M, fm ? 0 : 1, a.At, d.Mk, d.Np, d.Mk, 0, s));
+    HIP_TRY(copy2d<T>(A, lda, d.M, d.N, fm ? 1 : 0, a.Am, d.Np, d.Mj, d.Np, 0, s));
+    if (p.kl) HIP_TRY(kl_scale_dict<T>(a.At, d.Mk, d.M, d.Np, eps, a.Akl, s));
+    return ST_OK;
+}
+int prepare_dict_fused(const DictArrays<double>& a, const DictPlan& p, const double* B, int ldb, const Dims& d, bool fm,
+                       bool want_rowsum, hipStream_t s) {
+    if (p.fused) {
+        const FusedLayout fl = fused_layout(d.M, d.N, 1);
+        if (p.kl) {      // D/P operand order from the scaled dictionary, V' operand order from A
+            HIP_TRY(fused_pack_dict(fl, a.A1p, nullptr, a.Akl, d.Mk, d.Np, s));
+            HIP_TRY(fused_pack_dict(fl, nullptr, a.A2p, a.At, d.Mk, d.Np, s));
+        } else {
+            HIP_TRY(fused_pack_dict(fl, a.A1p, a.A2p, a.At, d.Mk, d.Np, s));
+        }
+        if (want_rowsum) HIP_TRY(fused_rowsum(a.At, d.Mk, d.M, d.N, a.rsum, s));
+    }
+    if (p.packed_b && B && a.Bt) {
+        // Bt[n][mb] (zero padded to 32 bins) -> B's V'-operand fragments
+        const FusedLayout flB = fused_layout(d.Mb, d.N, 1);
+        HIP_TRY(copy2d<double>(B, ldb, d.N, d.Mb, fm ? 0 : 1, a.Bt, 32, d.Np, 32, 0, s));
+        HIP_TRY(fused_pack_dict(flB, a.B1p, a.B2p, a.Bt, 32, d.Np, s));
+    }
+    return ST_OK;
+}
+// the arrays of a prepared dictionary (arithmetic type T); `skip`: bytes of staging in front of them
+template <typename T> DictArrays<T> dict_arrays(const evc_dict* dk, size_t skip) {
+    const Dims dd = make_dims((int)sizeof(T), dk->M, dk->N, 1, 1, dk->Mb);
+    Carver c{static_cast<char*>(dk->mem), skip};
+    return take_dict<T>(c, dd, dict_plan<T>(dk->M, dk->Mb, dk->N, dk->loss, true));
+}
+template <typename T> DictArrays<T> dict_arrays_at(void* mem, size_t skip, int M, int Mb, int N, int loss) {
+    const Dims dd = make_dims((int)sizeof(T), M, N, 1, 1, Mb);
+    Carver c{static_cast<char*>(mem), skip};
+    return take_dict<T>(c, dd, dict_plan<T>(M, Mb, N, loss, true));
+}
+// staging of a float32 dictionary that rides the float64 fused kernels: A and B widened once
+size_t dict_f64_staging(int M, int Mb, int N) {
+    return ((((size_t)N * M + (size_t)N * Mb) * sizeof(double) + 512) + 255) & ~size_t(255);
+}
+
+template <typename T> size_t dict_image_bytes(int M, int Mb, int N, int loss, size_t skip) {
+    const Dims dd = make_dims((int)sizeof(T), M, N, 1, 1, Mb);
+    Carver c{nullptr, skip};
+    take_dict<T>(c, dd, dict_plan<T>(M, Mb, N, loss, true));
+    return (c.off + 255) & ~size_t(255);
+}
+
+template <typename T>
+int dict_prepare_typed(const T* A, int lda, const T* B, int ldb, int M, int Mb, int N, bool fm, int loss, double eps,
+                              void* mem, size_t skip, hipStream_t s) {
+    const Dims dd = make_dims((int)sizeof(T), M, N, 1, 1, Mb);
+    const DictPlan p = dict_plan<T>(M, Mb, N, loss, true);
+    Carver c{static_cast<char*>(mem), skip};
+    const DictArrays<T> a = take_dict<T>(c, dd, p);
+    int st = prepare_dict<T>(a, p, A, lda, B, ldb, dd, fm, eps, true, s);
+    if (st) return st;
+    if (B && a.Bc) HIP_TRY(copy2d<T>(B, ldb, N, Mb, fm ? 0 : 1, a.Bc, Mb, N, Mb, 0, s));
+    if (p.wide) {
+        const WideLayout fl = wide_layout(M, N, 1, 256, 0, 0);
+        HIP_TRY(wide_pack_dict(fl, p.kl ? reinterpret_cast<const float*>(a.Akl) : reinterpret_cast<const float*>(a.At),
+                               reinterpret_cast<const float*>(a.At), dd.Mk, dd.Np, a.Aw, s));
+    }
     return ST_OK;
 }
 
@@ -196,11 +327,13 @@ int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_sol
     // iteration if the update reaches the same floating-point fixed point, i.e. with correctly rounded
     // quotients (reserved bit 1 asks for them explicitly)
     const int exact_div = (o.stop_rule == EVC_STOP_PYMF || (o.reserved & 2)) ? 1 : 0;
-    if (o.loss == EVC_LOSS_KL) {     // D/P operand order from the scaled dictionary, V' operand order from A
-        HIP_TRY(fused_pack_dict(w.fl, w.fb.A1p, nullptr, w.Akl, d.Mk, d.Np, s));
-        HIP_TRY(fused_pack_dict(w.fl, nullptr, w.fb.A2p, w.At, d.Mk, d.Np, s));
-    } else {
-        HIP_TRY(fused_pack_dict(w.fl, w.fb.A1p, w.fb.A2p, w.At, d.Mk, d.Np, s));
+    if (!o.dict) {     // (a prepared dictionary holds the fragments already)
+        DictArrays<double> da{};
+        da.At = w.At; da.Akl = w.Akl; da.A1p = w.fb.A1p; da.A2p = w.fb.A2p; da.rsum = w.fb.rsum;
+        DictPlan pl{};
+        pl.fused = true; pl.kl = o.loss == EVC_LOSS_KL;
+        int st = prepare_dict_fused(da, pl, nullptr, 0, d, true, false, s);
+        if (st) return st;
     }
     HIP_TRY(fused_pack_frames(w.fl, w.fb.Xp, w.Xt, d.Mk, s));
     // few frame tiles (one or two utterances): several workgroups share a tile and split the exemplars
@@ -225,7 +358,7 @@ int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_sol
     fb.init_const = 0;
     if (o.init_mode != EVC_INIT_GIVEN) {
         if (fb.all_c >= 1 && o.iters > 0 && !(o.check_every > 0 && o.stop_rule == EVC_STOP_SKLEARN)) {
-            HIP_TRY(fused_rowsum(w.At, d.Mk, d.M, d.N, fb.rsum, s));
+            if (!o.dict) HIP_TRY(fused_rowsum(w.At, d.Mk, d.M, d.N, fb.rsum, s));
             fb.init_const = 1;
         } else {
             HIP_TRY(fused_fill_h(w.fl, fb.Hp, d.N, d.T_, w.u, s));
@@ -291,9 +424,11 @@ int finish_fused<double>(const Workspace<double>& w, const Dims& d, const evc_so
     if (!y) return ST_OK;
     if (w.packed_synth) {
         // Bt[n][mb] (zero padded to 32 bins) -> B's V'-operand fragments -> pre-pass -> Y
-        HIP_TRY(copy2d<double>(static_cast<const double*>(y->B), y->ldb, d.N, y->Mb, fm ? 0 : 1, w.Bt, 32, d.Np,
-                               32, 0, s));
-        HIP_TRY(fused_pack_dict(w.flB, w.B1p, w.B2p, w.Bt, 32, d.Np, s));
+        if (!y->b_packed) {
+            HIP_TRY(copy2d<double>(static_cast<const double*>(y->B), y->ldb, d.N, y->Mb, (fm || y->b_rows) ? 0 : 1, w.Bt, 32,
+                                   d.Np, 32, 0, s));
+            HIP_TRY(fused_pack_dict(w.flB, w.B1p, w.B2p, w.Bt, 32, d.Np, s));
+        }
         HIP_TRY(fused_synthesize(w.flB, w.B2p, w.fb.Hp, w.Yp, w.u, d.N, d.T_, y->Mb,
                                  static_cast<double*>(y->Y), y->ldy, fm ? 1 : 0, s));
         return ST_OK;
@@ -349,8 +484,16 @@ WideWs carve_wide(void* base, const Dims& d, int n_slots, int n_cus, bool with_s
     w.bytes = (c.off + 255) & ~size_t(255);
     return w;
 }
+// Batches of fewer than ~300 frame tiles (about seven utterances) stay on the two-contraction path: with so few
+// frames the exemplar ranges of a frame group must be many (23 for one utterance) and the dependency hops of the
+// task queue (publish, reduce, gather: measured ~40 us per iteration) outweigh what the fusion saves - 90 against
+// 47 us per iteration for one utterance, 139 / 132 for four, 226 / 241 for eight, 334 / 457 for sixteen
+// (profiles/r03_wide_tuning.md).  The tuning bits (ranges, wavefronts) force the fused kernel at any size.
+constexpr int WIDE_MIN_TILES = 300;
 bool use_wide(int M, int N, int T_, int dtype, int algo, int reserved) {
-    return !(reserved & EVC_FLAG_NO_FUSED) && wide_supported(M, N, T_, dtype, algo);
+    if ((reserved & EVC_FLAG_NO_FUSED) || !wide_supported(M, N, T_, dtype, algo)) return false;
+    const bool forced = ((reserved >> 8) & 0xff) != 0 || ((reserved >> 16) & 0xf) != 0;
+    return forced || (T_ + 15) / 16 >= WIDE_MIN_TILES;
 }
 
 int solve_wide(const float* A, int lda, const float* X, int ldx, float* H, int ldh, int M, int N, int T_,
@@ -373,12 +516,24 @@ int solve_wide(const float* A, int lda, const float* X, int ldx, float* H, int l
     else
         HIP_TRY(utt_single(w.u, T_, s));
     HIP_TRY(utt_setup(w.u, n_utt, T_, d.Tp, o.iters, s));
-    HIP_TRY(copy2d<float>(A, lda, N, M, fm ? 0 : 1, w.At, d.Mk, d.Np, d.Mk, 0, s));
+    SynthArgs ydict;
+    if (o.dict) {                 // the block images (and B) come from the prepared dictionary
+        const DictArrays<float> ext = dict_arrays<float>(o.dict, 0);
+        w.fb.Aw = ext.Aw;
+        if (y && o.dict->Mb > 0) {
+            ydict = *y;
+            ydict.B = ext.Bc; ydict.ldb = o.dict->Mb; ydict.b_rows = 1;
+            y = &ydict;
+        }
+        inf->prepared = 1;
+    } else {
+        HIP_TRY(copy2d<float>(A, lda, N, M, fm ? 0 : 1, w.At, d.Mk, d.Np, d.Mk, 0, s));
+        if (kl) HIP_TRY(kl_scale_dict<float>(w.At, d.Mk, M, d.Np, o.eps, w.Akl, s));
+        HIP_TRY(wide_pack_dict(fl, kl ? w.Akl : w.At, w.At, d.Mk, d.Np, w.fb.Aw, s));
+    }
     HIP_TRY(copy2d<float>(X, ldx, T_, M, fm ? 0 : 1, w.Xt, d.Mk, d.Tp, d.Mk, 0, s));
-    if (kl) HIP_TRY(kl_scale_dict<float>(w.At, d.Mk, M, d.Np, o.eps, w.Akl, s));
     if (o.init_mode == EVC_INIT_SKLEARN) HIP_TRY(utt_sklearn_h0<float>(w.Xt, d.Mk, M, N, w.u, n_utt, s));
     else if (o.init_mode == EVC_INIT_CONST) HIP_TRY(utt_const_h0(w.u, n_utt, o.init_value, s));
-    HIP_TRY(wide_pack_dict(fl, kl ? w.Akl : w.At, w.At, d.Mk, d.Np, w.fb.Aw, s));
     HIP_TRY(wide_pack_x(fl, w.Xt, d.Mk, d.Tp, w.fb.Xw, s));
     const int init_const = o.init_mode == EVC_INIT_GIVEN ? 0 : 1;
     if (!init_const) HIP_TRY(wide_import_h(fl, w.fb.Hw, H, ldh, fm ? 1 : 0, T_, N, s));
@@ -458,9 +613,19 @@ int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int 
     int algo = o.algo == EVC_ALGO_AUTO ? EVC_ALGO_FACTORED : o.algo;
     const int n_slots = n_slots_for(o.iters, o.check_every);
     if (n_slots > MAX_SLOTS) return ST_UNSUPPORTED;
-    const bool fused = use_fused(M, N, T_, o.dtype, algo) && !(o.reserved & 1);
-    Workspace<T> w = carve<T>(ws, d, algo, MAX_SLOTS, fused);
+    const bool fused = use_fused(M, N, T_, sizeof(T) == 8 ? EVC_F64 : EVC_F32, algo) && !(o.reserved & 1);
+    // dictionary arrays: from the prepared image (float32 callers riding the float64 kernels: behind its staging)
+    DictArrays<T> ext{};
+    if (o.dict) ext = dict_arrays<T>(o.dict, (sizeof(T) == 8 && o.dict->dtype == EVC_F32) ? dict_f64_staging(M, o.dict->Mb, N) : 0);
+    Workspace<T> w = carve<T>(ws, d, algo, MAX_SLOTS, fused, o.dict ? &ext : nullptr);
     if (w.bytes > ws_bytes) return ST_WORKSPACE;
+    inf->prepared = o.dict ? 1 : 0;
+    SynthArgs ydict;              // synthesis from the prepared copy of B
+    if (o.dict && y && o.dict->Mb > 0) {
+        ydict = *y;
+        ydict.B = ext.Bc; ydict.ldb = o.dict->Mb; ydict.b_rows = 1; ydict.b_packed = ext.B2p ? 1 : 0;
+        y = &ydict;
+    }
     w.u.n_slots = n_slots;
     const bool fm = (o.layout == EVC_FRAME_MAJOR);
 
@@ -473,11 +638,16 @@ int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int 
 
     // ---- import the caller's matrices into zero-padded frames-as-rows workspace arrays ----
     // At[n][m], Am[m][n], Xt[t][m], Ht[t][n]
-    HIP_TRY(copy2d<T>(A, lda, N, M, fm ? 0 : 1, w.At, d.Mk, d.Np, d.Mk, 0, s));
-    HIP_TRY(copy2d<T>(A, lda, M, N, fm ? 1 : 0, w.Am, d.Np, d.Mj, d.Np, 0, s));
-    HIP_TRY(copy2d<T>(X, ldx, T_, M, fm ? 0 : 1, w.Xt, d.Mk, d.Tp, d.Mk, 0, s));
     const bool kl = (o.loss == EVC_LOSS_KL);
-    if (kl) HIP_TRY(kl_scale_dict<T>(w.At, d.Mk, M, d.Np, o.eps, w.Akl, s));
+    if (!o.dict) {
+        DictArrays<T> da{};
+        da.At = w.At; da.Am = w.Am; da.Akl = w.Akl;
+        DictPlan pl{};
+        pl.kl = kl;
+        int st = prepare_dict<T>(da, pl, A, lda, nullptr, 0, d, fm, o.eps, false, s);
+        if (st) return st;
+    }
+    HIP_TRY(copy2d<T>(X, ldx, T_, M, fm ? 0 : 1, w.Xt, d.Mk, d.Tp, d.Mk, 0, s));
     if (o.init_mode == EVC_INIT_SKLEARN) HIP_TRY(utt_sklearn_h0<T>(w.Xt, d.Mk, M, N, w.u, n_utt, s));
     else if (o.init_mode == EVC_INIT_CONST) HIP_TRY(utt_const_h0(w.u, n_utt, o.init_value, s));
 
@@ -683,13 +853,14 @@ static int solve_f32_on_f64(const void* A, int lda, const void* X, int ldx, void
     double* H64 = c.take<double>((size_t)T * N);
     double* B64 = c.take<double>((size_t)N * Mb);
     double* Y64 = c.take<double>((size_t)T * Mb);
-    HIP_TRY((cvt2d<float, double>(static_cast<const float*>(A), lda, aR, aC, A64, aC, s)));
+    if (!o.dict) HIP_TRY((cvt2d<float, double>(static_cast<const float*>(A), lda, aR, aC, A64, aC, s)));
     HIP_TRY((cvt2d<float, double>(static_cast<const float*>(X), ldx, xR, xC, X64, xC, s)));
     if (H && o.init_mode == EVC_INIT_GIVEN)
         HIP_TRY((cvt2d<float, double>(static_cast<const float*>(H), ldh, hR, hC, H64, hC, s)));
     SynthArgs y64{};
     if (y) {
-        HIP_TRY((cvt2d<float, double>(static_cast<const float*>(y->B), y->ldb, bR, bC, B64, bC, s)));
+        if (!(o.dict && o.dict->Mb > 0))
+            HIP_TRY((cvt2d<float, double>(static_cast<const float*>(y->B), y->ldb, bR, bC, B64, bC, s)));
         y64 = SynthArgs{B64, (int)bC, Y64, (int)yC, Mb};
     }
     evc_solve_opts o64 = o;
@@ -701,6 +872,66 @@ static int solve_f32_on_f64(const void* A, int lda, const void* X, int ldx, void
     if (H) HIP_TRY((cvt2d<double, float>(H64, hC, hR, hC, static_cast<float*>(H), ldh, s)));
     if (y) HIP_TRY((cvt2d<double, float>(Y64, yC, yR, yC, static_cast<float*>(y->Y), y->ldy, s)));
     if (n_iter_out || err_out) HIP_TRY(hipStreamSynchronize(s));    // those calls are synchronous: so are H and Y
+    return ST_OK;
+}
+
+// ---- prepared dictionaries ----
+size_t evc_dict_bytes(int M, int Mb, int N, int dtype, int loss) {
+    if (M < 1 || Mb < 0 || N < 1) return 0;
+    if (loss != EVC_LOSS_FROBENIUS && loss != EVC_LOSS_KL) return 0;
+    if (dtype == EVC_F64) return dict_image_bytes<double>(M, Mb, N, loss, 0);
+    if (dtype != EVC_F32) return 0;
+    if (f32_rides_f64(M, N, 1, EVC_ALGO_FACTORED, 0))     // widened once, then the float64 image
+        return dict_image_bytes<double>(M, Mb, N, loss, dict_f64_staging(M, Mb, N));
+    return dict_image_bytes<float>(M, Mb, N, loss, 0);
+}
+
+int evc_dict_prepare(const void* A, int lda, const void* B, int ldb, int M, int Mb, int N, int layout, int dtype, int loss,
+                     double eps, void* mem, size_t mem_bytes, evc_dict* dict, evc_stream_t stream) {
+    if (!A || !mem || !dict || M < 1 || N < 1 || Mb < 0 || (Mb > 0) != (B != nullptr)) return ST_BADARG;
+    if (layout != EVC_FRAME_MAJOR && layout != EVC_BIN_MAJOR) return ST_BADARG;
+    if (bad_ld(layout, lda, N, M) || (B && bad_ld(layout, ldb, N, Mb))) return ST_BADARG;
+    if (loss == EVC_LOSS_KL && !(eps > 0.0)) return ST_UNSUPPORTED;
+    const size_t need = evc_dict_bytes(M, Mb, N, dtype, loss);
+    if (need == 0) return ST_BADARG;
+    if (mem_bytes < need || (reinterpret_cast<uintptr_t>(mem) & 255)) return ST_WORKSPACE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool fm = layout == EVC_FRAME_MAJOR;
+    int st;
+    if (dtype == EVC_F64) {
+        st = dict_prepare_typed<double>(static_cast<const double*>(A), lda, static_cast<const double*>(B), ldb, M, Mb, N, fm,
+                                        loss, eps, mem, 0, s);
+        if (!st) {
+            const Dims dd = make_dims(8, M, N, 1, 1, Mb);
+            st = prepare_dict_fused(dict_arrays_at<double>(mem, 0, M, Mb, N, loss), dict_plan<double>(M, Mb, N, loss, true),
+                                    static_cast<const double*>(B), ldb, dd, fm, true, s);
+        }
+    } else if (f32_rides_f64(M, N, 1, EVC_ALGO_FACTORED, 0)) {
+        // widen A and B once (compact rows in the caller's orientation), then the float64 image behind them
+        const size_t skip = dict_f64_staging(M, Mb, N);
+        Carver c{static_cast<char*>(mem), 0};
+        double* A64 = c.take<double>((size_t)N * M);
+        double* B64 = c.take<double>((size_t)N * Mb);
+        const long aR = fm ? N : M, aC = fm ? M : N, bR = fm ? N : Mb, bC = fm ? Mb : N;
+        HIP_TRY((cvt2d<float, double>(static_cast<const float*>(A), lda, aR, aC, A64, aC, s)));
+        if (B) HIP_TRY((cvt2d<float, double>(static_cast<const float*>(B), ldb, bR, bC, B64, bC, s)));
+        st = dict_prepare_typed<double>(A64, (int)aC, B ? B64 : nullptr, (int)bC, M, Mb, N, fm, loss, eps, mem, skip, s);
+        if (!st) {
+            const Dims dd = make_dims(8, M, N, 1, 1, Mb);
+            st = prepare_dict_fused(dict_arrays_at<double>(mem, skip, M, Mb, N, loss), dict_plan<double>(M, Mb, N, loss, true),
+                                    B ? B64 : nullptr, (int)bC, dd, fm, true, s);
+        }
+    } else {
+        st = dict_prepare_typed<float>(static_cast<const float*>(A), lda, static_cast<const float*>(B), ldb, M, Mb, N, fm,
+                                       loss, eps, mem, 0, s);
+    }
+    if (st) return st;
+    dict->struct_bytes = (int)sizeof(evc_dict);
+    dict->magic = DICT_MAGIC;
+    dict->M = M; dict->Mb = Mb; dict->N = N; dict->dtype = dtype; dict->loss = loss; dict->reserved = 0;
+    dict->eps = loss == EVC_LOSS_KL ? eps : 0.0;
+    dict->mem = mem;
+    dict->bytes = need;
     return ST_OK;
 }
 
@@ -731,12 +962,23 @@ static int solve_checked(const void* A, int lda, const void* X, int ldx, void* H
         if (n_iter_out) for (int i = 0; i < n_utt; ++i) n_iter_out[i] = 0;
         return ST_OK;
     }
-    if (!A || !X || !workspace) return ST_BADARG;
+    const evc_dict* dk = o.dict;
+    if (dk) {         // a prepared dictionary replaces the A (and B) arguments
+        if (dk->struct_bytes != (int)sizeof(evc_dict) || dk->magic != DICT_MAGIC || !dk->mem) return ST_BADARG;
+        if (dk->M != M || dk->N != N || dk->dtype != o.dtype || dk->loss != o.loss) return ST_BADARG;
+        if (o.loss == EVC_LOSS_KL && dk->eps != o.eps) return ST_BADARG;
+        if (y && dk->Mb > 0 && dk->Mb != y->Mb) return ST_BADARG;
+        if (dk->bytes < evc_dict_bytes(M, dk->Mb, N, dk->dtype, dk->loss)) return ST_BADARG;
+        // a float32 dictionary with M <= 32 was widened for the float64 fused kernels: only that route is prepared
+        if (o.dtype == EVC_F32 && f32_rides_f64(M, N, T, EVC_ALGO_FACTORED, 0) && !f32_rides_f64(M, N, T, o.algo, o.reserved))
+            return ST_UNSUPPORTED;
+    }
+    if ((!dk && !A) || !X || !workspace) return ST_BADARG;
     if (!H && (!y || o.init_mode == EVC_INIT_GIVEN)) return ST_BADARG;   // H may be omitted by evc_nmf_convert only
-    if (bad_ld(o.layout, lda, N, M) || bad_ld(o.layout, ldx, T, M) || (H && bad_ld(o.layout, ldh, T, N)))
+    if ((!dk && bad_ld(o.layout, lda, N, M)) || bad_ld(o.layout, ldx, T, M) || (H && bad_ld(o.layout, ldh, T, N)))
         return ST_BADARG;
-    if (y && (!y->B || !y->Y || bad_ld(o.layout, y->ldb, N, y->Mb) || bad_ld(o.layout, y->ldy, T, y->Mb)))
-        return ST_BADARG;
+    if (y && (!y->Y || bad_ld(o.layout, y->ldy, T, y->Mb))) return ST_BADARG;
+    if (y && !(dk && dk->Mb > 0) && (!y->B || bad_ld(o.layout, y->ldb, N, y->Mb))) return ST_BADARG;
     if (utt_offsets) {
         if (utt_offsets[0] != 0 || utt_offsets[n_utt] != T) return ST_BADARG;
         for (int i = 0; i < n_utt; ++i)

@@ -41,7 +41,7 @@ namespace evc {
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WIDE_KL = 100;                   // update mode besides the four eps modes
-constexpr long WIDE_SPIN_LIMIT = 1L << 24;     // polls of ~0.25 us: seconds; only a wedged device gets there
+constexpr long WIDE_SPIN_LIMIT = 1L << 25;     // polls of >= 0.1 us: seconds; only a wedged device gets there
 
 struct WideArgs {
     const float* Aw;         // [NB][2][MT][64][4]  per exemplar block: D-operand image, then V'-operand image
@@ -82,6 +82,17 @@ __device__ __forceinline__ unsigned ld_ctr(const unsigned* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Diagnostic builds only (tools/ubench/wide_bench.hip, -DEVC_WIDE_STAMP): thread 0 of a workgroup stamps the
+// 100 MHz real-time counter at the phase boundaries of every task into a buffer of its own.
+#ifdef EVC_WIDE_STAMP
+__device__ unsigned long long* evc_wide_dbg = nullptr;        // [tasks of the launch][8]
+#define WSTAMP(k) do { if (tid == 0 && evc_wide_dbg) evc_wide_dbg[(size_t)tk * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define WNOTE(k, v) do { if (tid == 0 && evc_wide_dbg) evc_wide_dbg[(size_t)tk * 8 + (k)] = (unsigned long long)(v); } while (0)
+#else
+#define WSTAMP(k)
+#define WNOTE(k, v)
+#endif
+
 template <int MT, int W>
 __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
     constexpr int IMG = 2 * MT * 1024;                    // bytes of one block's two operand images
@@ -111,7 +122,7 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
             unsigned ok = 1u;
             long spins = 0;
             while (ld_ctr(ctr) < need) {
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(2);
                 ++spins;
                 if ((spins & 63) == 0 && __hip_atomic_load(a.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
                     ok = 0u;
@@ -151,26 +162,44 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
         const unsigned idx = reduce ? rem - GC : rem;
         const int g = (int)(idx / c), e = (int)(idx - (unsigned)g * c);
         const unsigned par = (unsigned)(it & 1);
+        WSTAMP(0);
+        WNOTE(6, (reduce ? 1u : 0u) | ((unsigned)blockIdx.x << 8));
+        WNOTE(7, ((unsigned long long)it << 32) | (unsigned)(g * 256 + e));
 
         if (reduce) {
             // ---- reduce task: slice e of the group's V' = sum over the c ranges, in range order ----
             if (!wait_for(a.done + g, c * (unsigned)(it + 1))) break;
+            WSTAMP(1);
             const unsigned U = W * MT * 64;                       // 16-byte units of a group's partial
             const unsigned lo = (unsigned)((unsigned long)e * U / c), hi = (unsigned)((unsigned long)(e + 1) * U / c);
             const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.Vpart + ((size_t)(par * a.G + g) * c) * U * 4, c * U * 16u);
             const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.Vsum + (size_t)(par * a.G + g) * U * 4, U * 16u);
             for (unsigned un = lo + tid; un < hi; un += W * 64) {
-                f32x4 acc = ld_sc1(rin, un * 16u);
-                for (unsigned m = 1; m < c; ++m) acc += ld_sc1(rin, (m * U + un) * 16u);
+                // 24 loads in flight at a time (each is a memory round trip), summed in range order
+                f32x4 acc = f32x4{0, 0, 0, 0};
+                for (unsigned m0 = 0; m0 < c; m0 += 24) {
+                    f32x4 v[24];
+#pragma unroll
+                    for (unsigned k = 0; k < 24; ++k) {
+                        const unsigned m = m0 + k < c ? m0 + k : c - 1;
+                        v[k] = ld_sc1(rin, (m * U + un) * 16u);
+                    }
+#pragma unroll
+                    for (unsigned k = 0; k < 24; ++k)
+                        if (m0 + k < c) acc = (m0 + k) ? acc + v[k] : v[k];
+                }
                 st_sc1(rout, un * 16u, acc);
             }
+            WSTAMP(3);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            WSTAMP(4);
             if (tid == 0) {
                 __hip_atomic_fetch_add(a.done_r + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s_ctl[0] = nxt;
             }
             __syncthreads();
+            WSTAMP(5);
             continue;
         }
 
@@ -182,6 +211,7 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
         if (nb > 0) stage_block(j0, 0);       // (the dictionary does not depend on anybody: its first block is on its way
                                               // while the group's counter is polled)
         if (it > 0 && !wait_for(a.rmode ? a.done_r + g : a.done + g, c * (unsigned)it)) break;
+        WSTAMP(1);
 
         f32x4 Vin[MT], Vn[MT];
 #pragma unroll
@@ -239,10 +269,17 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                          // block j0 is in stage 0
+        WSTAMP(2);
 
+        // Every memory operation of a block step gets a whole step to complete: the next block's images and H / P
+        // tiles are requested at the top of the step, and the updated tile of the PREVIOUS step is stored there too
+        // (a write-through store issued in the middle of a step was not done at the barrier that ends it).
+        f32x4 hS = f32x4{0, 0, 0, 0};
+        bool have_s = false;
         for (int i = 0; i < nb; ++i) {
             const int jb = j0 + i;
             const char* sb = smem + (i & 1) * IMG;
+            if (on && have_s) st_sc1(rh, ((jb - 1) * 64 + lane) * 16u, hS);
             if (i + 1 < nb) {
                 stage_block(jb + 1, (i + 1) & 1);
                 if (on) {
@@ -251,24 +288,42 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
                 }
             }
             if (on) {
-                // D = A_j^T Vin: two accumulation chains (a single wavefront per SIMD cannot issue dependent MFMAs back to back)
+                // D = A_j^T Vin: two accumulation chains (a single wavefront per SIMD cannot issue dependent MFMAs back
+                // to back).  The fragments of the next pair of bin tiles are requested before the MFMAs of this pair
+                // issue (two register sets), and the first V' fragments before the last D pair: LDS latency runs beside
+                // the matrix pipe instead of in front of it.
+                constexpr int NP = (MT + 1) / 2;                  // pairs of bin tiles
+                const char* s2 = sb + MT * 1024;
+                auto frag = [&](const char* base, int u) {
+                    return *reinterpret_cast<const f32x4*>(base + ((u < MT ? u : MT - 1) * 64 + lane) * 16);
+                };
+                f32x4 fa[2][2];
                 f32x4 d0 = f32x4{c0, c0, c0, c0}, d1 = f32x4{0, 0, 0, 0};
-                if (!(kl && it == 0)) {
+                const bool do_d = !(kl && it == 0);
+                if (do_d) {
+                    fa[0][0] = frag(sb, 0);
+                    fa[0][1] = frag(sb, 1);
 #pragma unroll
-                    for (int u = 0; u + 1 < MT; u += 2) {
-                        const f32x4 a0 = *reinterpret_cast<const f32x4*>(sb + (u * 64 + lane) * 16);
-                        const f32x4 a1 = *reinterpret_cast<const f32x4*>(sb + ((u + 1) * 64 + lane) * 16);
+                    for (int pp = 0; pp < NP; ++pp) {
+                        const int u = 2 * pp;
+                        if (pp + 1 < NP) {
+                            fa[(pp + 1) & 1][0] = frag(sb, u + 2);
+                            fa[(pp + 1) & 1][1] = frag(sb, u + 3);
+                        } else {
+                            fa[(pp + 1) & 1][0] = frag(s2, 0);
+                            fa[(pp + 1) & 1][1] = frag(s2, 1);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            d0 = Mma<float>::mma(a0[r], Vin[u][r], d0);
-                            d1 = Mma<float>::mma(a1[r], Vin[u + 1][r], d1);
+                            d0 = Mma<float>::mma(fa[pp & 1][0][r], Vin[u][r], d0);
+                            if (u + 1 < MT) d1 = Mma<float>::mma(fa[pp & 1][1][r], Vin[u + 1][r], d1);
                         }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
-                    if (MT & 1) {
-                        const f32x4 a0 = *reinterpret_cast<const f32x4*>(sb + ((MT - 1) * 64 + lane) * 16);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) d0 = Mma<float>::mma(a0[r], Vin[MT - 1][r], d0);
-                    }
+                } else {
+                    fa[NP & 1][0] = frag(s2, 0);
+                    fa[NP & 1][1] = frag(s2, 1);
                 }
                 const f32x4 D = d0 + d1;
                 f32x4 hn;
@@ -277,7 +332,8 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
                     if (a.init_const) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) hn[r] = (jb * 16 + 4 * q + r < a.N) ? h0v : 0.f;
-                        st_sc1(rh, (jb * 64 + lane) * 16u, hn);
+                        hS = hn;
+                        have_s = true;
                     } else {
                         hn = hC;
                     }
@@ -307,24 +363,25 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) hn[r] = live ? hn[r] : hC[r];     // frozen (stopped utterance) / padding
-                    st_sc1(rh, (jb * 64 + lane) * 16u, hn);
+                    hS = hn;
+                    have_s = true;
                 }
-                // V' += A_j H'_j: neighbouring accumulators alternate
-                const char* s2 = sb + MT * 1024;
+                // V' += A_j H'_j: neighbouring accumulators alternate; same fragment pipeline (its first pair was
+                // requested during the last D pair)
 #pragma unroll
-                for (int u = 0; u + 1 < MT; u += 2) {
-                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(s2 + (u * 64 + lane) * 16);
-                    const f32x4 a1 = *reinterpret_cast<const f32x4*>(s2 + ((u + 1) * 64 + lane) * 16);
+                for (int pp = 0; pp < NP; ++pp) {
+                    const int u = 2 * pp, cur = (NP + pp) & 1;
+                    if (pp + 1 < NP) {
+                        fa[cur ^ 1][0] = frag(s2, u + 2);
+                        fa[cur ^ 1][1] = frag(s2, u + 3);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        Vn[u] = Mma<float>::mma(a0[r], hn[r], Vn[u]);
-                        Vn[u + 1] = Mma<float>::mma(a1[r], hn[r], Vn[u + 1]);
+                        Vn[u] = Mma<float>::mma(fa[cur][0][r], hn[r], Vn[u]);
+                        if (u + 1 < MT) Vn[u + 1] = Mma<float>::mma(fa[cur][1][r], hn[r], Vn[u + 1]);
                     }
-                }
-                if (MT & 1) {
-                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(s2 + ((MT - 1) * 64 + lane) * 16);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) Vn[MT - 1] = Mma<float>::mma(a0[r], hn[r], Vn[MT - 1]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             __syncthreads();            // (waits vmcnt(0): the next block has landed; everybody is done with this stage)
@@ -332,8 +389,10 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
             pC = pN;
         }
 
-        // publish the partial V' of this range
+        WSTAMP(3);
+        // publish the partial V' of this range (and the last block's activations)
         if (on) {
+            if (have_s) st_sc1(rh, ((j1 - 1) * 64 + lane) * 16u, hS);
             const __amdgpu_buffer_rsrc_t rv =
                 make_rsrc(a.Vpart + (((size_t)(par * a.G + g) * c + e) * W + w) * (TILE_B / 4), TILE_B);
 #pragma unroll
@@ -341,11 +400,13 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        WSTAMP(4);
         if (tid == 0) {
             __hip_atomic_fetch_add(a.done + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_ctl[0] = nxt;
         }
         __syncthreads();
+        WSTAMP(5);
     }
 }
 
@@ -483,7 +544,8 @@ WideLayout wide_layout(int M, int N, int T_, int n_cus, int c_req, int w_req) {
     f.W = w_req == 4 || w_req == 8 ? w_req : (f.TT >= 2 * n_cus ? 8 : 4);
     f.G = (f.TT + f.W - 1) / f.W;
     // ranges per frame group: enough tasks per iteration to keep every CU busy (none when the groups alone do)
-    int c = c_req > 0 ? c_req : (f.G >= n_cus ? 1 : (n_cus + f.G - 1) / f.G);
+    // (never more tasks per iteration than workgroups when the ranges are many: the surplus would wait a whole task)
+    int c = c_req > 0 ? c_req : (f.G >= n_cus ? 1 : (f.G * 4 >= n_cus ? (n_cus + f.G - 1) / f.G : n_cus / f.G));
     const int cmax = f.NB / 2 > 0 ? f.NB / 2 : 1;
     if (c > cmax) c = cmax;
     if (c > 64) c = 64;
@@ -506,6 +568,7 @@ WideCaps wide_caps(int M, int N, int T_, int n_cus) {
     const size_t tile = (size_t)a4.MT * 256, ttp = (size_t)round_up(a4.TT, 8);
     int c_cap = a4.c > a8.c ? a4.c : a8.c;
     if (a4.TT <= 4096 && c_cap < 8) c_cap = 8;
+    if (a4.TT <= 256) c_cap = 64;
     k.c_cap = c_cap;
     k.aw = a4.aw;
     k.xw = ttp * tile;

@@ -138,6 +138,75 @@ def _pick_dtype(dtype, *arrs):
     raise ValueError(f"unsupported dtype {dtype!r}")
 
 
+class PreparedDictionary:
+    """A dictionary imported once into the layouts the kernels read (evc_dict_prepare): pass it in place of `A` (and
+    leave `B` out) to solve_activations / convert.  The reference builds A and B once per run
+    (04_align_n_nmf.py:230-246,350-361); results are bitwise those of the unprepared calls."""
+
+    def __init__(self, handle, buf, layout, tdtype, dcode, device, loss, eps):
+        self.handle, self._buf = handle, buf           # the device image must outlive the handle's uses
+        self.layout, self.tdtype, self.dcode, self.device, self.loss, self.eps = layout, tdtype, dcode, device, loss, eps
+        self.M, self.Mb, self.N = int(handle.M), int(handle.Mb), int(handle.N)
+
+
+def prepare_dictionary(A, B=None, *, layout="bin_major", dtype=None, loss="frobenius", eps=None, device=None):
+    """Import A (and the parallel target dictionary B) once; see PreparedDictionary."""
+    torch = _torch()
+    device = require_device(device)
+    L = _lib.lib()
+    lay = _LAYOUTS[layout]
+    tdtype, dcode = _pick_dtype(dtype, A)
+    A_d, _ = _to_dev(A, tdtype, device)
+    M, N = A_d.shape if lay == _lib.BIN_MAJOR else A_d.shape[::-1]
+    Mb, B_d = 0, None
+    if B is not None:
+        B_d, _ = _to_dev(B, tdtype, device)
+        Mb, N2 = B_d.shape if lay == _lib.BIN_MAJOR else B_d.shape[::-1]
+        if N2 != N:
+            raise ValueError(f"A and B disagree on the number of exemplars: {N} vs {N2}")
+    lcode = _LOSSES[loss]
+    if eps is None:
+        eps = _EPS_DEFAULT["zero_replace"] if lcode == _lib.LOSS_KL else 0.0
+    nbytes = int(L.evc_dict_bytes(M, Mb, N, dcode, lcode))
+    if nbytes == 0:
+        raise ValueError("unsupported dictionary shape / dtype")
+    with torch.cuda.device(device):
+        buf = torch.empty(nbytes + 256, dtype=torch.uint8, device=device)
+        off = (-buf.data_ptr()) % 256
+        handle = _lib.Dict()
+        st = L.evc_dict_prepare(A_d.data_ptr(), _ld(A_d), B_d.data_ptr() if B_d is not None else None,
+                                _ld(B_d) if B_d is not None else 0, M, Mb, N, lay, dcode, lcode, float(eps),
+                                buf.data_ptr() + off, nbytes, C.byref(handle),
+                                C.c_void_p(torch.cuda.current_stream(device).cuda_stream))
+    _lib.check(st, "evc_dict_prepare")
+    return PreparedDictionary(handle, buf, lay, tdtype, dcode, device, lcode, float(eps))
+
+
+_dict_cache = {}
+
+
+def cached_dictionary(A, B=None, **kw):
+    """prepare_dictionary, remembered per (A, B) object identity: the compat surfaces take plain arrays, and a caller
+    converting utterance after utterance against one dictionary passes the same arrays again.  The arrays are held
+    weakly; an entry dies with them.  (Content is NOT hashed: mutate a dictionary in place and you must not use this.)"""
+    import weakref
+    key = (id(A), id(B) if B is not None else None, tuple(getattr(A, "shape", ())), str(getattr(A, "dtype", "")),
+           tuple(sorted((k, str(v)) for k, v in kw.items())))
+    ent = _dict_cache.get(key)
+    if ent is not None and ent[1]() is A and (B is None or ent[2]() is B):
+        return ent[0]
+    pd = prepare_dictionary(A, B, **kw)
+    try:
+        ra = weakref.ref(A, lambda _r, k=key: _dict_cache.pop(k, None))
+        rb = weakref.ref(B) if B is not None else None
+    except TypeError:
+        return pd
+    if len(_dict_cache) >= 8:
+        _dict_cache.pop(next(iter(_dict_cache)))
+    _dict_cache[key] = (pd, ra, rb)
+    return pd
+
+
 def workspace_bytes(M, N, T, n_utt=1, dtype="f64", algo="auto", Mb=0):
     _, code = _pick_dtype(dtype)
     return int(_lib.lib().evc_workspace_bytes(M, Mb, N, T, n_utt, code, _ALGOS[algo]))
@@ -154,11 +223,15 @@ def solve_activations(A, X, H0=None, **kw):
     return _solve(A, X, H0, None, **kw)
 
 
-def convert(A, X, B, H0=None, *, want_h=True, **kw):
+def convert(A, X, B=None, H0=None, *, want_h=True, **kw):
     """Activation solve followed by the synthesis Y = B H in one launch sequence
     (factorize() + convert() of 04_align_n_nmf.py).  Returns (H, Y), or Y alone with
     want_h=False (the activations then never leave the solver's tile layout); with info=True
-    the info dict is appended."""
+    the info dict is appended.  `A` may be a PreparedDictionary made with B: then leave B out."""
+    if B is None:
+        if not (isinstance(A, PreparedDictionary) and A.Mb > 0):
+            raise ValueError("convert() needs B (or a prepared dictionary that holds it)")
+        B = True
     return _solve(A, X, H0, B, want_h=want_h, **kw)
 
 
@@ -172,25 +245,40 @@ def _solve(A, X, H0, B, *, layout="bin_major", iters=100, eps_mode="add", eps=No
     device = require_device(device)
     L = _lib.lib()
     lay = _LAYOUTS[layout]
+    pd = A if isinstance(A, PreparedDictionary) else None
+    if pd is not None:
+        if dtype is None:
+            dtype = pd.tdtype
+        if pd.device != device:
+            raise ValueError("the prepared dictionary lives on another device")
+        A = None
     tdtype, dcode = _pick_dtype(dtype, X, A)
-    A_d, _ = _to_dev(A, tdtype, device)
+    if pd is not None and (dcode != pd.dcode or _LOSSES[loss] != pd.loss):
+        raise ValueError("the prepared dictionary was made for another dtype / loss")
+    A_d = None if pd is not None else _to_dev(A, tdtype, device)[0]
     X_d, x_np = _to_dev(X, tdtype, device)
     if lay == _lib.BIN_MAJOR:
-        M, N = A_d.shape
+        M, N = (pd.M, pd.N) if pd is not None else A_d.shape
         M2, T = X_d.shape
         hshape = (N, T)
     else:
-        N, M = A_d.shape
+        N, M = (pd.N, pd.M) if pd is not None else A_d.shape
         T, M2 = X_d.shape
         hshape = (T, N)
     if M2 != M:
         raise ValueError(f"A and X disagree on the number of bins: {M} vs {M2}")
     Mb = 0
-    if B is not None:
+    B_d = None
+    if B is True:                 # convert() with the prepared dictionary's own B
+        if pd is None or pd.Mb == 0:
+            raise ValueError("convert() without B needs a prepared dictionary that holds B")
+        Mb = pd.Mb
+    elif B is not None:
         B_d, _ = _to_dev(B, tdtype, device)
         Mb, N2 = B_d.shape if lay == _lib.BIN_MAJOR else B_d.shape[::-1]
         if N2 != N:
             raise ValueError(f"A and B disagree on the number of exemplars: {N} vs {N2}")
+    if B is not None:
         yshape = (Mb, T) if lay == _lib.BIN_MAJOR else (T, Mb)
         Y_d = out_y if out_y is not None else torch.empty(yshape, dtype=tdtype, device=device)
     if init is None:
@@ -246,6 +334,10 @@ def _solve(A, X, H0, B, *, layout="bin_major", iters=100, eps_mode="add", eps=No
     sinfo = _lib.SolveInfo()
     sinfo.struct_bytes = C.sizeof(_lib.SolveInfo)
     opts.info = C.addressof(sinfo)
+    if pd is not None:
+        if loss in ("kl", "kullback-leibler") and opts.eps != pd.eps:
+            raise ValueError("the prepared dictionary's KL guard differs from this call's eps")
+        opts.dict = C.addressof(pd.handle)
     if loop_events is not None:     # (torch.cuda.Event, torch.cuda.Event), already created
         opts.ev_loop_start = int(loop_events[0].cuda_event)
         opts.ev_loop_stop = int(loop_events[1].cuda_event)
@@ -257,16 +349,18 @@ def _solve(A, X, H0, B, *, layout="bin_major", iters=100, eps_mode="add", eps=No
     ni_p = n_iter.ctypes.data_as(C.POINTER(C.c_int)) if info else None
     er_p = err.ctypes.data_as(C.POINTER(C.c_double)) if info else None
     h_ptr, h_ld = (H_d.data_ptr(), _ld(H_d)) if H_d is not None else (None, 0)
+    a_ptr, a_ld = (A_d.data_ptr(), _ld(A_d)) if A_d is not None else (None, 0)
     with torch.cuda.device(device), _workspace(ws_bytes, device) as ws:
         stream = torch.cuda.current_stream(device).cuda_stream
         if B is None:
             st = L.evc_nmf_solve(
-                A_d.data_ptr(), _ld(A_d), X_d.data_ptr(), _ld(X_d), h_ptr, h_ld,
+                a_ptr, a_ld, X_d.data_ptr(), _ld(X_d), h_ptr, h_ld,
                 M, N, T, off_ptr, n_utt, C.byref(opts), ws.data_ptr(), ws.numel(), ni_p, er_p,
                 C.c_void_p(stream))
         else:
             st = L.evc_nmf_convert(
-                A_d.data_ptr(), _ld(A_d), X_d.data_ptr(), _ld(X_d), B_d.data_ptr(), _ld(B_d),
+                a_ptr, a_ld, X_d.data_ptr(), _ld(X_d), B_d.data_ptr() if B_d is not None else None,
+                _ld(B_d) if B_d is not None else 0,
                 h_ptr, h_ld, Y_d.data_ptr(), _ld(Y_d), M, Mb, N, T, off_ptr, n_utt, C.byref(opts),
                 ws.data_ptr(), ws.numel(), ni_p, er_p, C.c_void_p(stream))
     _lib.check(st, "evc_nmf_solve" if B is None else "evc_nmf_convert")

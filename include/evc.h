@@ -107,6 +107,7 @@ enum { EVC_LOSS_FROBENIUS = 0, EVC_LOSS_KL = 1 };
 enum { EVC_FLAG_NO_FUSED = 1, EVC_FLAG_EXACT_DIV = 2, EVC_FLAG_NO_EXCHANGE = 4, EVC_FLAG_NO_ALL_RESIDENT = 16 };
 
 struct evc_solve_info;
+struct evc_dict;
 typedef struct evc_solve_opts {
     int struct_bytes;  /* sizeof(evc_solve_opts), for forward compatibility */
     int dtype;         /* EVC_F64 | EVC_F32 */
@@ -137,6 +138,11 @@ typedef struct evc_solve_opts {
      * call returns with what the library actually ran.  No extra synchronisation: `redo` is known from the round trip an
      * exchanging solve performs anyway. */
     struct evc_solve_info* info;
+    /* optional prepared dictionary (host struct filled by evc_dict_prepare; NULL = import A / B from the caller's
+     * matrices on every call, as the reference's scripts effectively do).  With a prepared dictionary the A and B
+     * arguments of evc_nmf_solve / evc_nmf_convert are ignored (may be NULL); M, Mb, N, dtype, loss and layout-independent
+     * options must match what it was prepared for, else the call returns -1. */
+    const struct evc_dict* dict;
 } evc_solve_opts;
 
 /* the kernel that carried the iteration loop of a solve */
@@ -161,8 +167,33 @@ typedef struct evc_solve_info {
     int reserved;
 } evc_solve_info;
 
+/* A dictionary imported once.  The reference builds A and B once per run (04_align_n_nmf.py:230-246,350-361) and the
+ * dictionary is fixed across utterances; every evc_nmf_solve / evc_nmf_convert call nevertheless has to bring the caller's
+ * matrices into the layouts its kernels read (zero-padded transposes, MFMA operand fragments, KL column scaling, row
+ * sums).  evc_dict_prepare does that once into caller-owned device memory; calls that pass the handle
+ * in evc_solve_opts.dict skip it (results are bitwise those of the unprepared call).  The struct is plain host data:
+ * copyable, nothing to free besides `mem`, which the caller owns and must keep alive and unmodified while it is used. */
+typedef struct evc_dict {
+    int struct_bytes;  /* sizeof(evc_dict), set by evc_dict_prepare */
+    int magic;
+    int M, Mb, N;      /* Mb = 0: no target dictionary B was given (evc_nmf_convert then needs its B argument) */
+    int dtype, loss, reserved;
+    double eps;        /* KL: the guard the column sums were formed with (must equal evc_solve_opts.eps) */
+    void* mem;         /* device memory, evc_dict_bytes() bytes, 256-byte aligned */
+    size_t bytes;
+} evc_dict;
+
 int evc_version(void);
 const char* evc_strerror(int status);
+
+/* bytes of device memory a prepared dictionary of this size needs (0: invalid arguments) */
+size_t evc_dict_bytes(int M, int Mb, int N, int dtype, int loss);
+/* Import A (M x N) and, if B != NULL, B (Mb x N), both in `layout`, into `mem` and fill *dict.  Asynchronous on `stream`
+ * (the handle may be used by later calls on the same stream at once).  eps: the KL guard (ignored for Frobenius).
+ * The image serves every algebra and kernel route of evc_nmf_solve / evc_nmf_convert (the Gram matrix of
+ * EVC_ALGO_GRAM / LITERAL is still formed per call). */
+int evc_dict_prepare(const void* A, int lda, const void* B, int ldb, int M, int Mb, int N, int layout, int dtype,
+                     int loss, double eps, void* mem, size_t mem_bytes, evc_dict* dict, evc_stream_t stream);
 
 /* number of GPUs visible to the library (hipGetDeviceCount); <0 on failure */
 int evc_device_count(void);

@@ -32,12 +32,16 @@ def test_struct_mirror_matches_header_fields():
     hdr = open(os.path.join(ROOT, "include", "evc.h")).read()
     body = hdr[hdr.index("typedef struct evc_solve_opts {"):hdr.index("} evc_solve_opts;")]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-    fields = re.findall(r"\b(?:int|double|void\*|struct evc_solve_info\*)\s+([a-z_0-9]+);", body)
+    fields = re.findall(r"\b(?:int|double|void\*|struct evc_solve_info\*|const struct evc_dict\*)\s+([a-z_0-9]+);", body)
     assert fields == [f[0] for f in _lib.SolveOpts._fields_]
     body = hdr[hdr.index("typedef struct evc_solve_info {"):hdr.index("} evc_solve_info;")]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     assert re.findall(r"\bint\s+([a-z_0-9]+);", body) == [f[0] for f in _lib.SolveInfo._fields_]
     assert C.sizeof(_lib.SolveInfo) == 32
+    body = hdr[hdr.index("typedef struct evc_dict {"):hdr.index("} evc_dict;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = [n for grp in re.findall(r"\b(?:int|double|void\*|size_t)\s+([a-zA-Z_0-9, ]+);", body) for n in grp.replace(" ", "").split(",")]
+    assert names == [f[0] for f in _lib.Dict._fields_]
     # kernel ids of the header <-> the names the Python side reports
     ids = dict((n.lower(), int(v)) for n, v in re.findall(r"EVC_KERNEL_([A-Z_0-9]+) = (\d+)", hdr))
     assert ids == {"none": 0, "gemm_nt": 1, "gemm2": 2, "fused_mu": 3, "fused_res": 4, "fused_all": 5, "fused_wide": 6}

@@ -5,7 +5,9 @@ Every case enters through the C ABI (evc_nmf_solve / evc_nmf_convert) and is com
 on the same float32 inputs.  Tolerance: float32 trajectories of different summation orders drift apart at about
 K sqrt(N) 6e-8, hence rtol 2e-3 with an absolute floor of 1e-6 max|H| (north_star asks 1e-4 of the float64 path).
 The exemplar ranges per frame group (c) and the wavefronts per workgroup (W) are forced through the tuning bits so
-that every dependency pattern of the task queue runs: no split, the direct sum of 2-4 partials, the reduce tasks."""
+that every dependency pattern of the task queue runs: no split, the direct sum of 2-4 partials, the reduce tasks.
+(Small batches are routed to the two-contraction path by default - evc_api.hip, use_wide - so the cases here force
+the fused kernel through those bits; `fused_w=4` alone means "this kernel, automatic ranges".)"""
 import numpy as np
 import pytest
 
@@ -34,10 +36,10 @@ def sk_want(o, A32, X32, K, l1=0.0):
 
 
 @pytest.mark.parametrize("M,N,T,K,c,w", [
-    (201, 256, 64, 20, 0, 0), (201, 256, 64, 20, 1, 4), (201, 256, 64, 20, 2, 8), (201, 250, 50, 20, 3, 4),
-    (201, 1000, 688, 30, 0, 0), (201, 1000, 688, 30, 6, 4), (201, 1000, 100, 30, 8, 8), (201, 1000, 100, 30, 4, 8),
-    (33, 300, 100, 25, 0, 0), (64, 512, 130, 25, 4, 0), (100, 512, 130, 25, 5, 0), (150, 200, 33, 25, 0, 8),
-    (208, 4096, 688, 20, 0, 0), (201, 17, 5, 10, 0, 0), (201, 4096, 1, 15, 0, 0),
+    (201, 256, 64, 20, 0, 4), (201, 256, 64, 20, 1, 4), (201, 256, 64, 20, 2, 8), (201, 250, 50, 20, 3, 4),
+    (201, 1000, 688, 30, 0, 4), (201, 1000, 688, 30, 6, 4), (201, 1000, 100, 30, 8, 8), (201, 1000, 100, 30, 4, 8),
+    (33, 300, 100, 25, 0, 4), (64, 512, 130, 25, 4, 0), (100, 512, 130, 25, 5, 0), (150, 200, 33, 25, 0, 8),
+    (208, 4096, 688, 20, 0, 8), (201, 17, 5, 10, 0, 4), (201, 4096, 1, 15, 0, 8), (201, 512, 5000, 12, 0, 0),
 ])
 def test_wide_kernel_against_the_oracle(M, N, T, K, c, w):
     import exemplars_vc_amd as evc
@@ -67,7 +69,7 @@ def test_wide_other_surfaces_and_convert(layout, eps_mode, eps):
                       algo="factored")
     tr = (lambda z: z) if layout == "bin_major" else (lambda z: np.ascontiguousarray(z.T))
     H, Y, info = evc.convert(tr(A32), tr(X32), tr(B32), tr(H0), layout=layout, iters=30, eps_mode=eps_mode, eps=eps,
-                             info=True)
+                             info=True, fused_w=4)
     assert info["kernel"] == "k_fused_wide"
     H, Y = (H, Y) if layout == "bin_major" else (H.T, Y.T)
     check(H, want)
@@ -85,7 +87,7 @@ def test_wide_l1_and_the_stop_rule_per_utterance():
     offs = [0, 100, 130, 230]
     H, info = evc.solve_activations(W_rows, X_rows, layout="frame_major", iters=150, eps_mode="zero_replace",
                                     init="sklearn", check_every=10, stop_rule="sklearn", tol=1e-3, utt_offsets=offs,
-                                    info=True)
+                                    info=True, fused_w=4)
     assert info["kernel"] == "k_fused_wide" and info["launches"] >= 2
     for u in range(3):
         a, b = offs[u], offs[u + 1]
@@ -94,7 +96,7 @@ def test_wide_l1_and_the_stop_rule_per_utterance():
         check(H[a:b], act, rtol=5e-3)
     act, _, _ = o.sklearn_mu_fixed_dictionary(X_rows.astype(np.float64), W_rows.astype(np.float64), 40, 0.0, l1_reg=2.01)
     Hl = evc.solve_activations(W_rows, X_rows, layout="frame_major", iters=40, eps_mode="zero_replace", init="sklearn",
-                               l1=2.01)
+                               l1=2.01, fused_w=8)
     check(Hl, act)
 
 
@@ -107,7 +109,7 @@ def test_wide_kl():
     act, _, _ = o.sklearn_mu_fixed_dictionary_kl(X_rows.astype(np.float64), W_rows.astype(np.float64), 40, 0.0)
     for c in (0, 3, 6):
         Hk, info = evc.solve_activations(W_rows, X_rows, layout="frame_major", iters=40, eps_mode="zero_replace",
-                                         init="sklearn", loss="kl", fused_c=c, info=True)
+                                         init="sklearn", loss="kl", fused_c=c, fused_w=4, info=True)
         assert info["kernel"] == "k_fused_wide"
         check(Hk, act, rtol=5e-3)
 
@@ -131,16 +133,29 @@ def test_wide_repeatable_and_independent_of_the_batch():
 
 
 def test_wide_real_audio_golden():
-    """the |Re STFT| fixture made from the reference's own audio with the installed scikit-learn (tools/make_golden.py)"""
+    """the |Re STFT| fixture made from the reference's own audio with the installed scikit-learn (tools/make_golden.py),
+    float32 as the script's flow is, through this kernel: same stop iteration, H within float32 drift"""
     import exemplars_vc_amd as evc
-    from exemplars_vc_amd.compat.factorize import _factorize
-    import warnings
     g = load_golden(GOLDEN + "/sklearn_audio_stft.npz")
     X, W = g["X_rows"].astype(np.float32), g["W_rows"].astype(np.float32)
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        H = _factorize(X, W, tol=float(g["tol"]))
-    assert H.dtype == np.float32 and H.shape == g["H"].shape
-    # (the float32 trajectory may stop one check later or earlier than the float64 one: compare with the float64
-    # oracle run on the float32 inputs to the iteration count the device reports when they differ)
-    check(H, g["H"], rtol=2e-2)
+    H, info = evc.solve_activations(W, X, layout="frame_major", iters=int(g["max_iter"]), eps_mode="zero_replace",
+                                    init="sklearn", check_every=10, stop_rule="sklearn", tol=float(g["tol"]), fused_w=4,
+                                    info=True)
+    assert info["kernel"] == "k_fused_wide" and H.dtype == np.float32
+    assert int(info["n_iter"][0]) == int(g["n_iter"])
+    check(H.T, g["H"], rtol=2e-2)
+
+
+def test_routing_by_batch_size():
+    """few frames: the two-contraction path (the task queue's dependency hops cost more than the fusion saves);
+    from about seven utterances on: the fused kernel.  float64 and M <= 32 are not this kernel's."""
+    import exemplars_vc_amd as evc
+    o = oracle()
+    p = o.synth_problem(201, 256, 4800, seed=1)
+    A32, X32 = p["A"].astype(np.float32), p["X"].astype(np.float32)
+    kw = dict(iters=3, eps_mode="zero_replace", init="sklearn", info=True)
+    assert evc.solve_activations(A32, X32[:, :688], **kw)[1]["kernel"] == "k_gemm2"
+    assert evc.solve_activations(A32, X32, **kw)[1]["kernel"] == "k_fused_wide"
+    assert evc.solve_activations(A32, X32, fused=False, **kw)[1]["kernel"] == "k_gemm2"
+    assert evc.solve_activations(p["A"], p["X"], **kw)[1]["kernel"] == "k_gemm_nt"
+    assert evc.solve_activations(A32[:25], X32[:25], **kw)[1]["kernel"].startswith("k_fused_")

@@ -33,7 +33,7 @@ def main():
                           eps=float(np.finfo(np.float32).eps), algo="factored")
         t0 = time.time()
         got, info = evc.solve_activations(A32, X32, iters=K, eps_mode="zero_replace", init="sklearn", fused_c=c,
-                                          fused_w=w, info=True)
+                                          fused_w=w or 4, info=True)
         dt = time.time() - t0
         r = rel(got.astype(np.float64), want)
         ok = r < 2e-3 and info["kernel"] == "k_fused_wide"
@@ -48,7 +48,7 @@ def main():
                       eps=1e-9, algo="factored")
     for lay in ("bin_major", "frame_major"):
         tr = (lambda z: z) if lay == "bin_major" else (lambda z: np.ascontiguousarray(z.T))
-        H, Y = evc.convert(tr(A32), tr(X32), tr(B32), tr(H0), layout=lay, iters=30, eps_mode="add")
+        H, Y = evc.convert(tr(A32), tr(X32), tr(B32), tr(H0), layout=lay, iters=30, eps_mode="add", fused_w=4)
         H, Y = (H, Y) if lay == "bin_major" else (H.T, Y.T)
         r, ry = rel(H.astype(np.float64), want), rel(Y.astype(np.float64), B32.astype(np.float64) @ want)
         ok = r < 2e-3 and ry < 2e-3
@@ -58,14 +58,14 @@ def main():
     X_rows, W_rows = np.ascontiguousarray(X32.T), np.ascontiguousarray(A32.T)
     act, n_ref, _ = o.sklearn_mu_fixed_dictionary(X_rows.astype(np.float64), W_rows.astype(np.float64), 150, 1e-3)
     H, info = evc.solve_activations(W_rows, X_rows, layout="frame_major", iters=150, eps_mode="zero_replace",
-                                    init="sklearn", check_every=10, stop_rule="sklearn", tol=1e-3, info=True)
+                                    init="sklearn", check_every=10, stop_rule="sklearn", tol=1e-3, info=True, fused_w=4)
     r = rel(H.astype(np.float64), act)
     ok = r < 5e-3 and int(info["n_iter"][0]) == n_ref
     bad += not ok
     print(f"stop rule: n_iter {int(info['n_iter'][0])} vs {n_ref}, rel={r:.2e} {'ok' if ok else 'FAIL'}", flush=True)
     actk, nk, _ = o.sklearn_mu_fixed_dictionary_kl(X_rows.astype(np.float64), W_rows.astype(np.float64), 40, 0.0)
     Hk = evc.solve_activations(W_rows, X_rows, layout="frame_major", iters=40, eps_mode="zero_replace", init="sklearn",
-                               loss="kl")
+                               loss="kl", fused_w=4)
     r = rel(Hk.astype(np.float64), actk)
     ok = r < 5e-3
     bad += not ok
