@@ -15,7 +15,7 @@ import warnings
 
 import numpy as np
 
-from ..solver import solve_activations, synthesize
+from ..solver import convert as _solve_and_synthesize, solve_activations, synthesize
 
 try:  # same warning class the reference would raise, when scikit-learn is present
     from sklearn.exceptions import ConvergenceWarning
@@ -63,6 +63,12 @@ def _factorize(X, W, beta_loss="kullback-leibler", tol=1e-4, *, device=None, alg
     1.1920929e-7, and every 10 iterations the loop stops when the Frobenius error decreased by
     less than `tol` (relative to the initial error); at most 150 iterations.
     """
+    return _factorize_impl(X, W, beta_loss, tol, device, algo, honor_beta_loss, hint, False)[0]
+
+
+def _factorize_impl(X, W, beta_loss, tol, device, algo, honor_beta_loss, hint, with_recon):
+    """_factorize; with_recon: also H.T @ W (T x M), the reconstruction the WORLD branch's residual needs
+    (04_align_n_nmf.py:292-294), formed by the same launch sequence from the device-resident activations."""
     # 04_align_n_nmf.py:210 overrides `beta_loss` with "frobenius" whatever the caller passed;
     # honor_beta_loss=True runs the loss that was asked for (sklearn's KL update, SURVEY 8f-4)
     loss = beta_loss if honor_beta_loss else "frobenius"
@@ -80,14 +86,18 @@ def _factorize(X, W, beta_loss="kullback-leibler", tol=1e-4, *, device=None, alg
         warnings.warn("X has negative entries; the multiplicative update is only meaningful for "
                       "non-negative data (scikit-learn does not check X on this route)",
                       RuntimeWarning, stacklevel=2)
-    act, info = solve_activations(
-        W, X, layout="frame_major", iters=MAX_ITER, eps_mode="zero_replace", init="sklearn",
-        check_every=CHECK_EVERY if tol > 0 else 0, stop_rule="sklearn" if tol > 0 else "none",
-        tol=tol, algo=algo, device=device, info=True, loss=loss, cooperative=_exchange_allowed(hint))
+    kw = dict(layout="frame_major", iters=MAX_ITER, eps_mode="zero_replace", init="sklearn",
+              check_every=CHECK_EVERY if tol > 0 else 0, stop_rule="sklearn" if tol > 0 else "none",
+              tol=tol, algo=algo, device=device, info=True, loss=loss, cooperative=_exchange_allowed(hint))
+    recon = None
+    if with_recon:      # Y = "B" H with the SOURCE dictionary in B's place: H never makes a round trip
+        act, recon, info = _solve_and_synthesize(W, X, W, **kw)
+    else:
+        act, info = solve_activations(W, X, **kw)
     if tol > 0 and int(info["n_iter"][0]) == MAX_ITER:
         warnings.warn(f"Maximum number of iterations {MAX_ITER} reached. Increase it to improve "
-                      "convergence.", ConvergenceWarning, stacklevel=2)
-    return act.T
+                      "convergence.", ConvergenceWarning, stacklevel=3)
+    return act.T, recon
 
 
 def factorize_utterances(X_list, W, tol=1e-4, *, device=None, algo="auto", max_iter=MAX_ITER, hint="throughput"):
@@ -177,24 +187,69 @@ def factorize(tobe_converted, src_feat, *, use_stft=True, tol=1e-4, device=None,
             H = artifacts.read_activations(hpath, False)
             if os.path.isfile(rpath):
                 return H, artifacts.read_residuals(rpath)
+    if residual not in ("reference", "log_ratio"):
+        raise ValueError("residual must be 'reference' or 'log_ratio'")
+    # The three streams are independent solves: each runs on a stream of its own, issued from a host thread of its
+    # own (one C3-sized solve fills about half of the chip), and its reconstruction H.T @ A comes out of the same
+    # launch sequence - the activations are downloaded once and never uploaded again.
+    recons = _solve_streams({n: v for n, v in streams.items() if "H_" + n not in H}, tol, device, hint, H)
     for name, (conv, A) in streams.items():
-        if "H_" + name not in H:
-            H["H_" + name] = _factorize(conv, A, tol=tol, device=device, hint=hint)
         # a cached H without its R: the residual is recomputed from it (:261-276; the expression there,
         # np.matmul(A, H), has its operands the wrong way round and cannot run - :292-294's is used)
-        recon = synthesize_rows(H["H_" + name], A, device=device)
+        recon = recons[name] if name in recons else synthesize_rows(H["H_" + name], A, device=device)
         if residual == "log_ratio":
             R["r_" + name] = np.log(np.maximum(conv, RESIDUAL_FLOOR)) - np.log(np.maximum(recon, RESIDUAL_FLOOR))
-        elif residual == "reference":
+        else:
             with np.errstate(invalid="ignore", divide="ignore"):
                 R["r_" + name] = np.log(recon - conv)
-        else:
-            raise ValueError("residual must be 'reference' or 'log_ratio'")
     if hpath is not None:
         if not os.path.isfile(hpath):
             artifacts.write_activations(hpath, H)
         artifacts.write_residuals(rpath, R)
     return H, R
+
+
+_side_streams = {}      # (device index, slot) -> torch.cuda.Stream: reused, so that the solver's per-stream scratch is too
+
+
+def _solve_streams(streams, tol, device, hint, H_out):
+    """solve every (conv, A) of `streams` concurrently: one host thread and one HIP stream each (the C ABI is
+    thread-safe for distinct streams, include/evc.h); fills H_out['H_<name>'] and returns {name: H.T @ A}.
+    Warnings raised in the threads are re-issued by the caller's thread; the first exception is re-raised."""
+    import threading
+    import torch
+    from ..solver import require_device
+    if not streams:
+        return {}
+    dev = require_device(device)
+    recons, caught, errors = {}, {}, {}
+
+    def work(name, conv, A, slot):
+        try:
+            torch.cuda.set_device(dev)
+            st = _side_streams.get((dev.index, slot))
+            if st is None:
+                st = _side_streams[(dev.index, slot)] = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(st), warnings.catch_warnings(record=True) as rec:
+                warnings.simplefilter("always")
+                h, r = _factorize_impl(conv, A, "frobenius", tol, dev, "auto", False, hint, True)
+            H_out["H_" + name], recons[name], caught[name] = h, r, rec
+        except BaseException as e:  # noqa: BLE001 - handed to the caller's thread
+            errors[name] = e
+
+    names = list(streams)
+    threads = [threading.Thread(target=work, args=(n, *streams[n], k + 1)) for k, n in enumerate(names[1:])]
+    for t in threads:
+        t.start()
+    work(names[0], *streams[names[0]], 0)
+    for t in threads:
+        t.join()
+    for n in names:
+        if n in errors:
+            raise errors[n]
+        for wmsg in caught.get(n, ()):
+            warnings.warn_explicit(wmsg.message, wmsg.category, wmsg.filename, wmsg.lineno)
+    return recons
 
 
 def convert(H, tar_feat, residual=None, *, use_stft=True, device=None, residual_mode="reference"):
