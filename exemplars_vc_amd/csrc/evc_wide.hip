@@ -84,6 +84,12 @@ __device__ __forceinline__ unsigned ld_ctr(const unsigned* p) {
 
 // Diagnostic builds only (tools/ubench/wide_bench.hip, -DEVC_WIDE_STAMP): thread 0 of a workgroup stamps the
 // 100 MHz real-time counter at the phase boundaries of every task into a buffer of its own.
+// -DEVC_WIDE_ABLATE=n (diagnostic, wrong results): what bounds a block step is found by taking one part out.
+// 1: no H / P loads and no H store (the update runs on what is in the registers); 2: the block loop re-reads the
+// first block's images (no LDS-DMA inside the loop); 3: both; 4: no update arithmetic (H' = H)
+#ifndef EVC_WIDE_ABLATE
+#define EVC_WIDE_ABLATE 0
+#endif
 #ifdef EVC_WIDE_STAMP
 __device__ unsigned long long* evc_wide_dbg = nullptr;        // [tasks of the launch][8]
 #define WSTAMP(k) do { if (tid == 0 && evc_wide_dbg) evc_wide_dbg[(size_t)tk * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -95,12 +101,18 @@ __device__ unsigned long long* evc_wide_dbg = nullptr;        // [tasks of the l
 
 template <int MT, int W>
 __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
+#ifdef EVC_WIDE_STAGGER          // diagnostic build: see "Stagger" below - measured slower, off
+    constexpr bool STAGGER = W == 8;
+#else
+    constexpr bool STAGGER = false;
+#endif
+    constexpr int NSTAGE = 3;                             // LDS stages of block images
     constexpr int IMG = 2 * MT * 1024;                    // bytes of one block's two operand images
     constexpr int NPIECE = 2 * MT;                        // 1 KiB LDS-DMA pieces per block
     constexpr int PPW = (NPIECE + W - 1) / W;             // pieces per wavefront
     constexpr unsigned TILE_B = MT * 1024;                // bytes of one V tile
-    extern __shared__ __attribute__((aligned(16))) char smem[];      // [2][IMG], then 16 bytes of control words
-    volatile unsigned* s_ctl = reinterpret_cast<volatile unsigned*>(smem + 2 * IMG);
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // [NSTAGE][IMG], then 16 bytes of control words
+    volatile unsigned* s_ctl = reinterpret_cast<volatile unsigned*>(smem + NSTAGE * IMG);
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, i16 = lane & 15;
     const unsigned GC = (unsigned)(a.G * a.c);
@@ -274,120 +286,171 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
         // Every memory operation of a block step gets a whole step to complete: the next block's images and H / P
         // tiles are requested at the top of the step, and the updated tile of the PREVIOUS step is stored there too
         // (a write-through store issued in the middle of a step was not done at the barrier that ends it).
-        f32x4 hS = f32x4{0, 0, 0, 0};
+        //
+        // Stagger (-DEVC_WIDE_STAGGER, W == 8; tried, measured, OFF): between two barriers every wavefront runs the same
+        // program, so a SIMD's two wavefronts multiply together and then run the update's ~50 VALU instructions
+        // together, the matrix pipe idle meanwhile (taking the update out saves 9 % of a step).  With wavefronts 4-7
+        // half a step late - in step i: V' of block i-1, then D and the update of block i; a block's images then live
+        // for two steps, hence three LDS stages - one wavefront's update runs beside the other's MFMAs.  Measured at
+        // the STFT flow, 16 utterances: 331 us of block steps per iteration against 312 without (256 VGPRs instead of
+        // 206, and the early half's first fragments of a step are no longer requested ahead): dropped.
+        constexpr int NP = (MT + 1) / 2;                  // pairs of bin tiles
+        constexpr bool no_mem = EVC_WIDE_ABLATE == 1 || EVC_WIDE_ABLATE == 3, no_dma = EVC_WIDE_ABLATE == 2 || EVC_WIDE_ABLATE == 3;
+        const bool late = STAGGER && w >= W / 2;          // (wave-uniform)
+        const bool do_d = !(kl && it == 0);
+        auto frag = [&](const char* base, int u) {
+            return *reinterpret_cast<const f32x4*>(base + ((u < MT ? u : MT - 1) * 64 + lane) * 16);
+        };
+        // Both products walk the bin tiles in pairs; the fragments of the next pair are requested before the MFMAs of
+        // this pair issue (two register sets), and the first pair of the NEXT product (`next`, if any) before the
+        // last pair's: LDS latency runs beside the matrix pipe.  q0/q1 carry that first pair from product to product.
+        f32x4 q0 = f32x4{0, 0, 0, 0}, q1 = q0;
+        auto product_d = [&](const char* img, bool preloaded, const char* next) -> f32x4 {
+            // D = A_j^T Vin: two accumulation chains (one wavefront per SIMD cannot issue dependent MFMAs back to back)
+            f32x4 fa[2][2];
+            f32x4 d0 = f32x4{c0, c0, c0, c0}, d1 = f32x4{0, 0, 0, 0};
+            fa[0][0] = preloaded ? q0 : frag(img, 0);
+            fa[0][1] = preloaded ? q1 : frag(img, 1);
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp) {
+                const int u = 2 * pp;
+                if (pp + 1 < NP) {
+                    fa[(pp + 1) & 1][0] = frag(img, u + 2);
+                    fa[(pp + 1) & 1][1] = frag(img, u + 3);
+                } else if (next) {
+                    fa[(pp + 1) & 1][0] = frag(next, 0);
+                    fa[(pp + 1) & 1][1] = frag(next, 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    d0 = Mma<float>::mma(fa[pp & 1][0][r], Vin[u][r], d0);
+                    if (u + 1 < MT) d1 = Mma<float>::mma(fa[pp & 1][1][r], Vin[u + 1][r], d1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            q0 = fa[NP & 1][0];
+            q1 = fa[NP & 1][1];
+            return d0 + d1;
+        };
+        auto product_v = [&](const char* img, const f32x4& hv, bool preloaded, const char* next) {
+            // V' += A_j H'_j: neighbouring accumulators alternate
+            f32x4 fa[2][2];
+            fa[0][0] = preloaded ? q0 : frag(img, 0);
+            fa[0][1] = preloaded ? q1 : frag(img, 1);
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp) {
+                const int u = 2 * pp;
+                if (pp + 1 < NP) {
+                    fa[(pp + 1) & 1][0] = frag(img, u + 2);
+                    fa[(pp + 1) & 1][1] = frag(img, u + 3);
+                } else if (next) {
+                    fa[(pp + 1) & 1][0] = frag(next, 0);
+                    fa[(pp + 1) & 1][1] = frag(next, 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    Vn[u] = Mma<float>::mma(fa[pp & 1][0][r], hv[r], Vn[u]);
+                    if (u + 1 < MT) Vn[u + 1] = Mma<float>::mma(fa[pp & 1][1][r], hv[r], Vn[u + 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            q0 = fa[NP & 1][0];
+            q1 = fa[NP & 1][1];
+        };
+        f32x4 hS = f32x4{0, 0, 0, 0};      // the tile to store at the top of the next step
         bool have_s = false;
+        // the update of block jb: H' from H, P and the denominator (iteration 0: the start values; P goes to memory)
+        auto update = [&](int jb, const f32x4& D) -> f32x4 {
+            f32x4 hn;
+            if (it == 0) {
+                if (a.init_const) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hn[r] = (jb * 16 + 4 * q + r < a.N) ? h0v : 0.f;
+                    hS = hn;
+                    have_s = true;
+                } else {
+                    hn = hC;
+                }
+                if (!kl) st_sc1(rp, (jb * 64 + lane) * 16u, D);
+            } else if (EVC_WIDE_ABLATE == 4) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hn[r] = hC[r] + 1e-30f * D[r];
+                hS = hn;
+                have_s = true;
+            } else {
+                switch (a.mode) {
+                    case EVC_EPS_ZERO_REPLACE:                       // sklearn _nmf.py:620-629
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) hn[r] = hC[r] * (pC[r] / (D[r] == 0.f ? a.eps : D[r]));
+                        break;
+                    case EVC_EPS_CLAMP:                              // deComP batch_mu.py
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) hn[r] = hC[r] * (pC[r] / (D[r] > a.eps ? D[r] : a.eps));
+                        break;
+                    case WIDE_KL:                                    // sklearn _nmf.py:556-606: H (.) (A/colsum)^T R
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) hn[r] = hC[r] * D[r];
+                        break;
+                    default:                                         // ADD (eps already in D), NONE: (h p) / d
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) hn[r] = (hC[r] * pC[r]) / D[r];
+                        break;
+                }
+                if (jb == n_edge) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hn[r] = (jb * 16 + 4 * q + r < a.N) ? hn[r] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hn[r] = live ? hn[r] : hC[r];     // frozen (stopped utterance) / padding
+                hS = hn;
+                have_s = true;
+            }
+            return hn;
+        };
+
+        f32x4 hP = f32x4{0, 0, 0, 0};      // late wavefronts: H' of the previous block, its V' product still to come
+        const char* s2P = nullptr;         // ... and that block's V' image
+        bool qa2 = false;                  // q0 / q1 hold the first fragment pair of that image
+        int st = 0;                        // LDS stage of block i
         for (int i = 0; i < nb; ++i) {
-            const int jb = j0 + i;
-            const char* sb = smem + (i & 1) * IMG;
-            if (on && have_s) st_sc1(rh, ((jb - 1) * 64 + lane) * 16u, hS);
+            const int jb = j0 + i, stn = st == NSTAGE - 1 ? 0 : st + 1;
+            const char* sb = smem + (no_dma ? 0 : st) * IMG;
+            const char* s2 = sb + MT * 1024;
+            if (on && have_s && !no_mem) st_sc1(rh, ((jb - 1) * 64 + lane) * 16u, hS);
             if (i + 1 < nb) {
-                stage_block(jb + 1, (i + 1) & 1);
-                if (on) {
+                if (!no_dma) stage_block(jb + 1, stn);
+                if (on && !no_mem) {
                     if (load_h) hN = ld_sc1(rh, ((jb + 1) * 64 + lane) * 16u);
                     if (load_p) pN = ld_sc1(rp, ((jb + 1) * 64 + lane) * 16u);
                 }
             }
             if (on) {
-                // D = A_j^T Vin: two accumulation chains (a single wavefront per SIMD cannot issue dependent MFMAs back
-                // to back).  The fragments of the next pair of bin tiles are requested before the MFMAs of this pair
-                // issue (two register sets), and the first V' fragments before the last D pair: LDS latency runs beside
-                // the matrix pipe instead of in front of it.
-                constexpr int NP = (MT + 1) / 2;                  // pairs of bin tiles
-                const char* s2 = sb + MT * 1024;
-                auto frag = [&](const char* base, int u) {
-                    return *reinterpret_cast<const f32x4*>(base + ((u < MT ? u : MT - 1) * 64 + lane) * 16);
-                };
-                f32x4 fa[2][2];
-                f32x4 d0 = f32x4{c0, c0, c0, c0}, d1 = f32x4{0, 0, 0, 0};
-                const bool do_d = !(kl && it == 0);
-                if (do_d) {
-                    fa[0][0] = frag(sb, 0);
-                    fa[0][1] = frag(sb, 1);
-#pragma unroll
-                    for (int pp = 0; pp < NP; ++pp) {
-                        const int u = 2 * pp;
-                        if (pp + 1 < NP) {
-                            fa[(pp + 1) & 1][0] = frag(sb, u + 2);
-                            fa[(pp + 1) & 1][1] = frag(sb, u + 3);
-                        } else {
-                            fa[(pp + 1) & 1][0] = frag(s2, 0);
-                            fa[(pp + 1) & 1][1] = frag(s2, 1);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            d0 = Mma<float>::mma(fa[pp & 1][0][r], Vin[u][r], d0);
-                            if (u + 1 < MT) d1 = Mma<float>::mma(fa[pp & 1][1][r], Vin[u + 1][r], d1);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                if (!late) {
+                    f32x4 D = f32x4{c0, c0, c0, c0};
+                    if (do_d) D = product_d(sb, false, s2);
+                    const f32x4 hn = update(jb, D);
+                    product_v(s2, hn, do_d, nullptr);
                 } else {
-                    fa[NP & 1][0] = frag(s2, 0);
-                    fa[NP & 1][1] = frag(s2, 1);
-                }
-                const f32x4 D = d0 + d1;
-                f32x4 hn;
-                if (it == 0) {
-                    // start values; P = A_j^T X goes to memory once
-                    if (a.init_const) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) hn[r] = (jb * 16 + 4 * q + r < a.N) ? h0v : 0.f;
-                        hS = hn;
-                        have_s = true;
-                    } else {
-                        hn = hC;
+                    bool qa1 = false;
+                    if (s2P) {
+                        product_v(s2P, hP, qa2, do_d ? sb : nullptr);
+                        qa1 = do_d;
                     }
-                    if (!kl) st_sc1(rp, (jb * 64 + lane) * 16u, D);
-                } else {
-                    switch (a.mode) {
-                        case EVC_EPS_ZERO_REPLACE:                       // sklearn _nmf.py:620-629
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) hn[r] = hC[r] * (pC[r] / (D[r] == 0.f ? a.eps : D[r]));
-                            break;
-                        case EVC_EPS_CLAMP:                              // deComP batch_mu.py
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) hn[r] = hC[r] * (pC[r] / (D[r] > a.eps ? D[r] : a.eps));
-                            break;
-                        case WIDE_KL:                                    // sklearn _nmf.py:556-606: H (.) (A/colsum)^T R
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) hn[r] = hC[r] * D[r];
-                            break;
-                        default:                                         // ADD (eps already in D), NONE: (h p) / d
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) hn[r] = (hC[r] * pC[r]) / D[r];
-                            break;
-                    }
-                    if (jb == n_edge) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) hn[r] = (jb * 16 + 4 * q + r < a.N) ? hn[r] : 0.f;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) hn[r] = live ? hn[r] : hC[r];     // frozen (stopped utterance) / padding
-                    hS = hn;
-                    have_s = true;
-                }
-                // V' += A_j H'_j: neighbouring accumulators alternate; same fragment pipeline (its first pair was
-                // requested during the last D pair)
-#pragma unroll
-                for (int pp = 0; pp < NP; ++pp) {
-                    const int u = 2 * pp, cur = (NP + pp) & 1;
-                    if (pp + 1 < NP) {
-                        fa[cur ^ 1][0] = frag(s2, u + 2);
-                        fa[cur ^ 1][1] = frag(s2, u + 3);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        Vn[u] = Mma<float>::mma(fa[cur][0][r], hn[r], Vn[u]);
-                        if (u + 1 < MT) Vn[u + 1] = Mma<float>::mma(fa[cur][1][r], hn[r], Vn[u + 1]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                    f32x4 D = f32x4{c0, c0, c0, c0};
+                    if (do_d) D = product_d(sb, qa1, s2);
+                    qa2 = do_d;
+                    hP = update(jb, D);
+                    s2P = s2;
                 }
             }
             __syncthreads();            // (waits vmcnt(0): the next block has landed; everybody is done with this stage)
             hC = hN;
             pC = pN;
+            st = stn;
         }
+        if (on && late && s2P) product_v(s2P, hP, qa2, nullptr);      // the late half's last V' product
 
         WSTAMP(3);
         // publish the partial V' of this range (and the last block's activations)
@@ -632,7 +695,7 @@ hipError_t wide_begin(const WideLayout& f, const WideBuffers& b, hipStream_t s) 
 
 template <int MT, int W>
 static hipError_t wide_launch(const WideArgs& a, unsigned grid, hipStream_t s) {
-    const size_t lds = 2 * (size_t)(2 * MT * 1024) + 16;
+    const size_t lds = 3 * (size_t)(2 * MT * 1024) + 16;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_wide<MT, W>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -159,3 +159,39 @@ def test_routing_by_batch_size():
     assert evc.solve_activations(A32, X32, fused=False, **kw)[1]["kernel"] == "k_gemm2"
     assert evc.solve_activations(p["A"], p["X"], **kw)[1]["kernel"] == "k_gemm_nt"
     assert evc.solve_activations(A32[:25], X32[:25], **kw)[1]["kernel"].startswith("k_fused_")
+
+
+@pytest.mark.parametrize("tag", ["f32", "f64"])
+def test_default_flow_at_dictionary_scale_real_audio(tag):
+    """The script's default flow at the size it runs it (SURVEY 8d real-audio variant; tools/make_golden_audio.py):
+    |Re STFT| of the reference's eight parallel SF1/TF1 utterances, DTW-aligned into a 4096-exemplar dictionary pair,
+    wav/SF1_100162.wav (688 frames) converted; expected values from the installed scikit-learn through the call of
+    04_align_n_nmf.py:212-213 (tol 1e-4: it stops after 140 iterations), in float32 and in float64.  Through the
+    drop-in surface: compat.factorize.factorize(use_stft=True) + convert()."""
+    import warnings
+    from exemplars_vc_amd.compat.factorize import factorize, convert
+    g32 = load_golden(GOLDEN + "/audio_stft_n4096_f32.npz")
+    g = g32 if tag == "f32" else load_golden(GOLDEN + "/audio_stft_n4096_f64.npz")
+    dt = np.float32 if tag == "f32" else np.float64
+    A, B, X = (g32[k].astype(dt) for k in ("A_rows", "B_rows", "X_rows"))
+    assert A.shape == (4096, 201) and X.shape == (688, 201)
+    # the dictionary as the script holds it: per-file lists of aligned frames (here: four "files" of 1024 pairs)
+    src = [{"real": A[i:i + 1024]} for i in range(0, 4096, 1024)]
+    tar = [{"real": B[i:i + 1024]} for i in range(0, 4096, 1024)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        H, R = factorize({"real": X}, src, use_stft=True, tol=float(g["tol"]))
+        Y = convert(H, tar, R, use_stft=True)
+    assert R is None and H["H_stft"].shape == (4096, 688) and H["H_stft"].dtype == dt and Y.shape == (688, 201)
+    if tag == "f64":
+        np.testing.assert_allclose(Y, g["Y_rows"], rtol=1e-8, atol=1e-12 * float(g["Y_rows"].max()))
+        np.testing.assert_allclose(H["H_stft"][:, :32], g["H_first32"], rtol=1e-7, atol=1e-14 * float(g["H_first32"].max()))
+    else:
+        # float32 trajectories of different summation orders drift: 140 iterations over N = 4096
+        np.testing.assert_allclose(Y, g["Y_rows"], rtol=2e-3, atol=1e-5 * float(g["Y_rows"].max()))
+        np.testing.assert_allclose(H["H_stft"][:, :32], g["H_first32"], rtol=2e-2, atol=1e-5 * float(g["H_first32"].max()))
+    # the same utterance through the solver with the stop rule visible: it stops where scikit-learn stopped
+    import exemplars_vc_amd as evc
+    _, info = evc.solve_activations(A, X, layout="frame_major", iters=int(g["max_iter"]), eps_mode="zero_replace",
+                                    init="sklearn", check_every=10, stop_rule="sklearn", tol=float(g["tol"]), info=True)
+    assert int(info["n_iter"][0]) == int(g["n_iter"]) == 140

@@ -10,7 +10,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import golden_files, load_golden
+from conftest import GOLDEN, golden_files, load_golden
 from oracle import evc_oracle as o
 
 
@@ -103,3 +103,18 @@ def test_griffin_lim_restatement_is_bit_exact(path):
     x, rmse = o.griffin_lim(g["mag"], int(g["n_fft"]), int(g["hop"]), int(g["iters"]), g["x0"])
     assert np.array_equal(x, g["x"])
     np.testing.assert_allclose(rmse, g["rmse"], rtol=1e-12)     # the reference prints repr-rounded floats
+
+
+def test_oracle_reproduces_the_dictionary_scale_audio_fixture():
+    """tests/golden/audio_stft_n4096_f64.npz (tools/make_golden_audio.py: installed scikit-learn, N = 4096, T = 688,
+    real audio): bit for bit.  The stop rule couples all frames of a call, so the whole utterance is run (about ten
+    seconds on 8 cores)."""
+    from oracle import evc_oracle as o
+    g32 = load_golden(os.path.join(GOLDEN, "audio_stft_n4096_f32.npz"))
+    g = load_golden(os.path.join(GOLDEN, "audio_stft_n4096_f64.npz"))
+    A, B, X = (g32[k].astype(np.float64) for k in ("A_rows", "B_rows", "X_rows"))
+    act, n_iter, _ = o.sklearn_mu_fixed_dictionary(X, A, int(g["max_iter"]), float(g["tol"]))
+    assert n_iter == int(g["n_iter"]) == 140
+    H = act.T          # the oracle returns scikit-learn's W (T x N); the script returns its transpose
+    assert np.array_equal(H[:, :32], g["H_first32"])
+    assert np.array_equal(o.s4_convert(H, B), g["Y_rows"])

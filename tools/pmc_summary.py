@@ -35,7 +35,11 @@ if "--json" in sys.argv:
     name = max((k for k in acc if tag in k), key=lambda k: sum(acc[k].get("SQ_INSTS_MFMA", [0])))
     c = {n: sum(v) / len(v) for n, v in acc[name].items()}
     w = 8 if dtype == "f64" else 4
-    if "k_fused_all" in name:       # H read once and written once per launch; nothing else streams
+    if "k_fused_wide" in name:      # H and P stream once per iteration (H read + written, P read); P and H0 written once
+        algorithmic = int(frames * N * w * (3 * K + 2))
+        note = ("k_fused_wide: per iteration H read and written and P read once, whole launch = K iterations + the "
+                "pass that forms P; dictionary blocks from L2, partial V' exchange not counted")
+    elif "k_fused_all" in name:     # H read once and written once per launch; nothing else streams
         algorithmic = frames * N * w * 2
         note = "k_fused_all: activations read once and written once per launch, dictionary fragments from L2"
     elif "k_fused_res" in name:     # every other exemplar tile streams (read + write) per iteration
