@@ -193,6 +193,11 @@ size_t gl_workspace_bytes(long T_total, int n_utt, int F, int hop, int iters) {
 // x: the utterances' signals back to back (utterance u: T_u hop + F samples at offset hop off[u] + u F); in = initial
 // signals (the reference draws randn), out = reconstructions.  off: host, n_utt + 1 frame offsets into `mag`.
 // rmse_host (host, [n_utt][iters], may be NULL): per-iteration sqrt(mean((x_new - x_old)^2)) of every utterance.
+__global__ void k_gl_single_offsets(int* off, int T_) {
+    off[0] = 0;
+    off[1] = T_;
+}
+
 hipError_t gl_run(const double* mag, long ldm, const int* off, int n_utt, int F, int hop, int iters, double* x,
                   void* ws, double* rmse_host, hipStream_t s) {
     const int G = gl_gap(F, hop);
@@ -212,7 +217,16 @@ hipError_t gl_run(const double* mag, long ldm, const int* off, int n_utt, int F,
     int* doff = reinterpret_cast<int*>(take(((size_t)n_utt + 2) / 2));
     int* row_src = reinterpret_cast<int*>(take(((size_t)d.Tp + 1) / 2));
 
-    hipError_t e = hipMemcpyAsync(doff, off, sizeof(int) * (n_utt + 1), hipMemcpyHostToDevice, s);
+    // The offsets reach the device by value for a single utterance (evc_griffin_lim hands a stack array: nothing
+    // may read it after this function returns); a batch's host array is copied asynchronously - the caller keeps it
+    // valid until the call returns (include/evc.h), and HIP stages a pageable source before hipMemcpyAsync returns.
+    hipError_t e = hipSuccess;
+    if (n_utt == 1) {
+        hipLaunchKernelGGL(k_gl_single_offsets, dim3(1), dim3(1), 0, s, doff, off[1]);
+        e = hipGetLastError();
+    } else {
+        e = hipMemcpyAsync(doff, off, sizeof(int) * (n_utt + 1), hipMemcpyHostToDevice, s);
+    }
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(xa, 0, sizeof(double) * d.Lp, s);
     if (e != hipSuccess) return e;

@@ -35,7 +35,12 @@
  *         the solve is redone without any exchange).  EVC_FLAG_NO_EXCHANGE keeps such a call fully
  *         asynchronous (at about half the speed for a lone utterance, ~10 % less for large batches).
  *   No global mutable state: calls on distinct streams/devices are independent and the
- *   caller's current device (hipSetDevice) is honoured.
+ *   caller's current device (hipSetDevice) is honoured.  Nothing is read from the process environment.
+ *   Host arrays (utt_offsets, frame_offsets, a_offsets / b_offsets) are consumed before the call returns: they are
+ *   copied to the device by hipMemcpyAsync from pageable memory, which HIP stages at enqueue time; keep them valid
+ *   until the call returns, not longer.
+ *   k_fused_all's exchange carries its arrival flag in the lowest mantissa bit of every partial sum it publishes
+ *   (readers clear it): each partial V' is truncated by at most one ulp, infinities and NaNs pass unchanged.
  */
 #ifndef EVC_H
 #define EVC_H

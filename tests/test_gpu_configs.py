@@ -384,3 +384,23 @@ def test_bench_gpus_flag_starts_the_ranks(tmp_path):
     assert r["config"]["frames_per_gpu"] < 109206 * 0.51, r
     assert r["redo_count"] == 0 and "k_fused_all" in r["config"]["kernel"], r
     assert r["value"] == pytest.approx(109206 * 2 / (r["ms_per_step"] * 2 / 1e3), rel=1e-6)
+
+
+def test_non_finite_partials_cross_the_exchange_unchanged():
+    """k_fused_all tags every published partial sum in its lowest mantissa bit; an infinite partial must
+    come out of the exchange as the same infinity (readers clear the bit), so that results for overflowing inputs do
+    not depend on which kernel ran.  One frame of X holds an inf: its activations go inf, then NaN - the same in the
+    kernels that exchange and in those that do not; the other frames are untouched."""
+    import exemplars_vc_amd as evc
+    o = oracle()
+    p = o.synth_problem(25, 4096, 688, seed=21)
+    X = p["X"].copy()
+    X[3, 100] = np.inf
+    kw = dict(iters=6, eps_mode="zero_replace", init="const", init_value=0.01, info=True)
+    a, ia = evc.solve_activations(p["A"], X, **kw)
+    b, ib = evc.solve_activations(p["A"], X, cooperative=False, **kw)
+    assert ia["kernel"] == "k_fused_all" and ia["exchange"] == 1 and ib["exchange"] == 0
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.isinf(a), np.isinf(b))
+    assert not np.isfinite(a[:, 100]).all() and np.isfinite(np.delete(a, 100, axis=1)).all()
+    fin = np.isfinite(a)
+    np.testing.assert_allclose(a[fin], b[fin], rtol=1e-10)
