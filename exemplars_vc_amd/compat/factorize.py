@@ -212,6 +212,12 @@ def factorize(tobe_converted, src_feat, *, use_stft=True, tol=1e-4, device=None,
 _side_streams = {}      # (device index, slot) -> torch.cuda.Stream: reused, so that the solver's per-stream scratch is too
 
 
+def _factorize_recon(conv, A, tol, device, hint):
+    """(H, H.T @ A) of one stream: `_factorize` plus the reconstruction, in one launch sequence (a seam of its own so
+    that the host-logic tests can put the oracle in its place)"""
+    return _factorize_impl(conv, A, "frobenius", tol, device, "auto", False, hint, True)
+
+
 def _solve_streams(streams, tol, device, hint, H_out):
     """solve every (conv, A) of `streams` concurrently: one host thread and one HIP stream each (the C ABI is
     thread-safe for distinct streams, include/evc.h); fills H_out['H_<name>'] and returns {name: H.T @ A}.
@@ -221,8 +227,12 @@ def _solve_streams(streams, tol, device, hint, H_out):
     from ..solver import require_device
     if not streams:
         return {}
-    dev = require_device(device)
     recons, caught, errors = {}, {}, {}
+    if not torch.cuda.is_available():      # nothing to overlap: the solve itself raises (there is no CPU fallback)
+        for n, (conv, A) in streams.items():
+            H_out["H_" + n], recons[n] = _factorize_recon(conv, A, tol, device, hint)
+        return recons
+    dev = require_device(device)
 
     def work(name, conv, A, slot):
         try:
@@ -232,7 +242,7 @@ def _solve_streams(streams, tol, device, hint, H_out):
                 st = _side_streams[(dev.index, slot)] = torch.cuda.Stream(device=dev)
             with torch.cuda.stream(st), warnings.catch_warnings(record=True) as rec:
                 warnings.simplefilter("always")
-                h, r = _factorize_impl(conv, A, "frobenius", tol, dev, "auto", False, hint, True)
+                h, r = _factorize_recon(conv, A, tol, dev, hint)
             H_out["H_" + name], recons[name], caught[name] = h, r, rec
         except BaseException as e:  # noqa: BLE001 - handed to the caller's thread
             errors[name] = e

@@ -120,6 +120,12 @@ def test_factorize_cache_semantics(tmp_path, monkeypatch, use_stft):
 
     monkeypatch.setattr(fz, "_factorize", counting)
     monkeypatch.setattr(fz, "synthesize_rows", lambda H, B, device=None: o.s4_convert(H, np.asarray(B)))
+
+    def counting_recon(conv, A, tol, device, hint):      # the WORLD branch's seam: H and H.T @ A from one call
+        H = counting(conv, A, tol=tol)
+        return H, o.s4_convert(H, np.asarray(A))
+
+    monkeypatch.setattr(fz, "_factorize_recon", counting_recon)
     rng = np.random.default_rng(5)
     if use_stft:
         src = [{"real": rng.random((6, 9)) - 0.3} for _ in range(2)]
