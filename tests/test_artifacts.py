@@ -172,6 +172,8 @@ def test_log_ratio_residual_extension(monkeypatch):
     reference): y_hat_target * y / y_hat_source on floored positives.  Host logic; the solve is the oracle."""
     monkeypatch.setattr(fz, "_factorize", _oracle_factorize)
     monkeypatch.setattr(fz, "synthesize_rows", lambda H, B, device=None: o.s4_convert(H, np.asarray(B)))
+    monkeypatch.setattr(fz, "_factorize_recon", lambda conv, A, tol, device, hint: (
+        _oracle_factorize(conv, A, tol=tol), o.s4_convert(_oracle_factorize(conv, A, tol=tol), np.asarray(A))))
     rng = np.random.default_rng(11)
     src = [{"sp": rng.random((6, 9)) + 0.1, "ap": rng.random((6, 9)) + 0.1, "f0": rng.random(6) + 0.1} for _ in range(2)]
     tar = [{"sp": rng.random((6, 9)) + 0.1, "ap": rng.random((6, 9)) + 0.1, "f0": rng.random(6) + 0.1} for _ in range(2)]
