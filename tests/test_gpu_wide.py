@@ -195,3 +195,72 @@ def test_default_flow_at_dictionary_scale_real_audio(tag):
     _, info = evc.solve_activations(A, X, layout="frame_major", iters=int(g["max_iter"]), eps_mode="zero_replace",
                                     init="sklearn", check_every=10, stop_rule="sklearn", tol=float(g["tol"]), info=True)
     assert int(info["n_iter"][0]) == int(g["n_iter"]) == 140
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_wide_random_shapes_against_the_two_contraction_path(seed):
+    """Differential test over seeded random shapes: the fused kernel (random ranges per group and wavefronts per
+    workgroup) against the two-contraction float32 path on the same call - ragged utterances, exemplar counts that
+    are not multiples of 16, both layouts, with the synthesis, error traces over several launches, KL."""
+    import exemplars_vc_amd as evc
+    o = oracle()
+    rng = np.random.default_rng(500 + seed)
+    M = int(rng.integers(33, 209))
+    N = int(rng.choice([int(rng.integers(40, 300)), int(rng.integers(300, 1500)), 16 * int(rng.integers(8, 80))]))
+    lens = [int(rng.integers(1, 200)) for _ in range(int(rng.integers(1, 6)))]
+    T = sum(lens)
+    p = o.synth_problem(M, N, T, seed=900 + seed)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    K = int(rng.integers(1, 20))
+    layout = "frame_major" if seed % 2 else "bin_major"
+    tr = (lambda a: np.ascontiguousarray(a.T.astype(np.float32))) if layout == "frame_major" else \
+        (lambda a: np.ascontiguousarray(a.astype(np.float32)))
+    kw = dict(layout=layout, iters=K, eps_mode=["zero_replace", "add", "clamp"][seed % 3],
+              init=["sklearn", "const"][seed % 2], utt_offsets=offs)
+    if kw["init"] == "const":
+        kw["init_value"] = 0.21
+    if seed % 4 == 3:
+        kw.update(check_every=4, info=True)
+    if seed % 5 == 2:
+        kw.update(loss="kl", eps_mode="zero_replace")
+    c, w = int(rng.integers(0, 9)), int(rng.choice([4, 8]))
+    got = evc.convert(tr(p["A"]), tr(p["X"]), tr(p["B"]), fused_c=c, fused_w=w, **kw)
+    want = evc.convert(tr(p["A"]), tr(p["X"]), tr(p["B"]), fused=False, **kw)
+    for g, wv, name in zip(got[:2], want[:2], ("H", "Y")):
+        g64, w64 = np.asarray(g, dtype=np.float64), np.asarray(wv, dtype=np.float64)
+        np.testing.assert_allclose(g64, w64, rtol=2e-3, atol=2e-6 * float(np.abs(w64).max()),
+                                   err_msg=f"seed {seed} M={M} N={N} lens={lens} K={K} c={c} w={w} {layout}: {name}")
+    if seed % 4 == 3:
+        assert got[2]["kernel"] == "k_fused_wide" and want[2]["kernel"] == "k_gemm2"
+        np.testing.assert_allclose(got[2]["err"], want[2]["err"], rtol=1e-3, atol=1e-5 * float(np.linalg.norm(p["X"])),
+                                   equal_nan=True)
+
+
+def test_wide_two_processes_share_the_card(tmp_path):
+    """The task queue needs no co-residency: two processes on one GPU, each running solves whose tasks wait on each
+    other's partial sums, both finish with correct results (a task only ever waits for tasks that hold earlier
+    tickets, i.e. that are running)."""
+    import os
+    import subprocess
+    import sys
+    script = tmp_path / "worker.py"
+    script.write_text(
+        "import sys, numpy as np\n"
+        f"sys.path.insert(0, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))})\n"
+        "import exemplars_vc_amd as evc\n"
+        "from oracle import evc_oracle as o\n"
+        "p = o.synth_problem(201, 1024, 688, seed=int(sys.argv[1]))\n"
+        "A, X = p['A'].astype(np.float32), p['X'].astype(np.float32)\n"
+        "want = evc.solve_activations(A, X, iters=20, eps_mode='zero_replace', init='sklearn', fused=False)\n"
+        "worst = 0.0\n"
+        "for i in range(3):\n"
+        "    got, info = evc.solve_activations(A, X, iters=20, eps_mode='zero_replace', init='sklearn', fused_w=4, info=True)\n"
+        "    assert info['kernel'] == 'k_fused_wide' and info['members'] > 4\n"
+        "    worst = max(worst, float(np.abs(got - want).max() / np.abs(want).max()))\n"
+        "print('WORST', worst)\n"
+        "assert worst < 1e-4, worst\n")
+    procs = [subprocess.Popen([sys.executable, str(script), str(k)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for k in (1, 2)]
+    outs = [pr.communicate(timeout=600)[0].decode() for pr in procs]
+    for pr, out in zip(procs, outs):
+        assert pr.returncode == 0 and "WORST" in out, out[-2000:]
