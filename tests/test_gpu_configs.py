@@ -145,8 +145,9 @@ def _c4_problem(n_utt=162, N=4096, M=25, seed=4):
 def test_c4_full_set_on_one_gpu():
     """The 162-utterance set (1.09e5 frames) through the shard driver with world_size 1: one batched launch
     sequence, the reference's per-call semantics per utterance (own init value, stop test every 10
-    iterations with tol=1e-4, own n_iter).  Utterances 1, 3 and 10 (216, 494 and 216 frames) are compared with
-    the scikit-learn restatement run on each of them alone."""
+    iterations with tol=1e-4, own n_iter).  Twelve utterances (three each of 216, 494, 497 and 513 frames, spread over
+    the set - the scikit-learn restatement evaluates the Gram algebra, 2 N^2 flop per frame-iteration, so the short
+    ones are sampled) are compared with the restatement run on each of them alone: same n_iter, same Y."""
     from exemplars_vc_amd.shard import convert_sharded
     o = oracle()
     p, Xs = _c4_problem()
@@ -156,7 +157,10 @@ def test_c4_full_set_on_one_gpu():
     assert len(out) == len(Xs)
     for i, (Y, n) in enumerate(out):
         assert Y.shape == (len(Xs[i]), 25) and np.isfinite(Y).all() and 10 <= n <= 100 and n % 10 == 0
-    for i in (1, 3, 10):
+    by_len = {L: [i for i in range(len(Xs)) if len(Xs[i]) == L] for L in (216, 494, 497, 513)}
+    sample = sorted(i for idx in by_len.values() for i in (idx[0], idx[len(idx) // 2], idx[-1]))
+    assert len(sample) == 12
+    for i in sample:
         act, n_ref, _ = o.sklearn_mu_fixed_dictionary(Xs[i], W, max_iter=100, tol=1e-4)
         assert out[i][1] == n_ref, (i, out[i][1], n_ref)
         assert_close64(out[i][0], act @ B, f"C4 utterance {i}")
