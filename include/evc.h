@@ -305,7 +305,7 @@ int evc_griffin_lim_batch(const void* mag, int ldm, const int* frame_offsets, in
  *   path_a/b  : device int arrays of sum_p (Ta_p + Tb_p) entries; pair p's path starts at
  *               a_offsets[p] + b_offsets[p] and has path_len[p] (device, n_pairs) entries
  *   total     : device, n_pairs doubles or NULL: accumulated cost of the last cell
- * Frames per utterance are limited by the LDS wavefront buffers (about 6800). */
+ * Frames per utterance are limited by the LDS border buffers of the tiled wavefront (7680). */
 size_t evc_dtw_workspace_bytes(const int* a_offsets, const int* b_offsets, int n_pairs);
 int evc_dtw_align(const void* A, int lda, const int* a_offsets, const void* B, int ldb,
                   const int* b_offsets, int D, int n_pairs, int* path_a, int* path_b, int* path_len,
