@@ -59,7 +59,7 @@ class SolveInfo(C.Structure):
 
 
 KERNEL_NAMES = {0: "none", 1: "k_gemm_nt", 2: "k_gemm2", 3: "k_fused_mu", 4: "k_fused_res", 5: "k_fused_all",
-                6: "k_fused_wide"}
+                6: "k_fused_wide", 7: "k_fused_wide64"}
 
 
 class EvcError(RuntimeError):

@@ -55,6 +55,7 @@ struct DictPlan {
     bool fused;          // float64 fused kernels (M <= 32): operand fragments, row sums
     bool packed_b;       // ... and B's fragments for the synthesis from packed tiles (1 <= Mb <= 32)
     bool wide;           // k_fused_wide's block images (float32, 32 < M <= 208)
+    bool wide64;         // k_fused_wide64's block images (float64, 208 < M <= 576, Frobenius)
     bool kl;             // the dictionary divided by its column sums
     bool bc;             // a compact exemplars-as-rows copy of B (prepared images: the caller's B is not consulted)
 };
@@ -65,6 +66,7 @@ template <typename T> struct DictArrays {
     double *B1p, *B2p;
     T* Bc;
     float* Aw;
+    double* Aw64;
 };
 template <typename T> DictPlan dict_plan(int M, int Mb, int N, int loss, bool prepared) {
     DictPlan p{};
@@ -72,6 +74,7 @@ template <typename T> DictPlan dict_plan(int M, int Mb, int N, int loss, bool pr
     p.fused = sizeof(T) == 8 && fused_supported(M, N, 1, EVC_F64);
     p.packed_b = p.fused && Mb >= 1 && Mb <= 32;
     p.wide = sizeof(T) == 4 && wide_supported(M, N, 1, EVC_F32, EVC_ALGO_FACTORED);
+    p.wide64 = sizeof(T) == 8 && wide64_supported(M, N, 1, EVC_F64, EVC_ALGO_FACTORED, loss);
     p.bc = prepared && Mb >= 1;
     return p;
 }
@@ -93,6 +96,7 @@ template <typename T> DictArrays<T> take_dict(Carver& c, const Dims& d, const Di
         a.B2p = c.take<double>(flB.a2);
     }
     if (p.wide) a.Aw = c.take<float>(wide_layout(d.M, d.N, 1, 256, 0, 0).aw);
+    if (p.wide64) a.Aw64 = c.take<double>(wide64_layout(d.M, d.N, 1, 256, 0).aw);
     if (p.bc) a.Bc = c.take<T>((size_t)d.N * d.Mb);
     return a;
 }
@@ -127,6 +131,7 @@ Workspace<T> carve(void* base, const Dims& d, int algo, int n_slots, bool fused,
     plan.fused = fused;
     plan.packed_b = fused && d.Mb >= 1 && d.Mb <= 32;
     plan.wide = false;
+    plan.wide64 = false;
     const DictArrays<T> da = ext ? *ext : take_dict<T>(c, d, plan);
     w.At = da.At;
     w.Am = da.Am;
@@ -300,6 +305,10 @@ int dict_prepare_typed(const T* A, int lda, const T* B, int ldb, int M, int Mb, 
         HIP_TRY(wide_pack_dict(fl, p.kl ? reinterpret_cast<const float*>(a.Akl) : reinterpret_cast<const float*>(a.At),
                                reinterpret_cast<const float*>(a.At), dd.Mk, dd.Np, a.Aw, s));
     }
+    if (p.wide64) {
+        const Wide64Layout fl = wide64_layout(M, N, 1, 256, 0);
+        HIP_TRY(wide_pack_dict(fl, reinterpret_cast<const double*>(a.At), nullptr, dd.Mk, dd.Np, a.Aw64, s));
+    }
     return ST_OK;
 }
 
@@ -441,10 +450,31 @@ int finish_fused<double>(const Workspace<double>& w, const Dims& d, const evc_so
 // The wide fused path (float32, 32 < M <= 208, FACTORED): k_fused_wide (evc_wide.hip).  One launch per
 // `check_every` iterations (a single launch when no residual is wanted); iteration 0 forms P and V = A H0.
 // ------------------------------------------------------------------------------------------------------
-struct WideWs {
-    float *At, *Akl, *Xt, *H0;
-    WideBuffers fb;
-    WideCaps caps;
+template <typename T> struct WideKind;
+template <> struct WideKind<float> {
+    typedef WideLayout Layout;
+    typedef WideBuffers Buffers;
+    typedef WideCaps Caps;
+    static constexpr int kernel = EVC_KERNEL_FUSED_WIDE;
+    static Layout layout(int M, int N, int T_, int n_cus, int c_req, int w_req) {
+        return wide_layout(M, N, T_, n_cus, c_req, w_req);
+    }
+    static Caps caps(int M, int N, int T_, int n_cus) { return wide_caps(M, N, T_, n_cus); }
+    static float* image(const DictArrays<float>& a) { return a.Aw; }
+};
+template <> struct WideKind<double> {
+    typedef Wide64Layout Layout;
+    typedef Wide64Buffers Buffers;
+    typedef Wide64Caps Caps;
+    static constexpr int kernel = EVC_KERNEL_FUSED_WIDE64;
+    static Layout layout(int M, int N, int T_, int n_cus, int c_req, int) { return wide64_layout(M, N, T_, n_cus, c_req); }
+    static Caps caps(int M, int N, int T_, int n_cus) { return wide64_caps(M, N, T_, n_cus); }
+    static double* image(const DictArrays<double>& a) { return a.Aw64; }
+};
+template <typename T> struct WideWs {
+    T *At, *Akl, *Xt, *H0;
+    typename WideKind<T>::Buffers fb;
+    typename WideKind<T>::Caps caps;
     double* err2;
     UttState u;
     size_t bytes;
@@ -456,20 +486,21 @@ int device_cus() {
         cus = 256;
     return cus;
 }
-WideWs carve_wide(void* base, const Dims& d, int n_slots, int n_cus, bool with_synth, bool kl) {
-    WideWs w{};
+template <typename T>
+WideWs<T> carve_wide(void* base, const Dims& d, int n_slots, int n_cus, bool with_synth, bool kl) {
+    WideWs<T> w{};
     Carver c{static_cast<char*>(base), 0};
-    w.caps = wide_caps(d.M, d.N, d.T_, n_cus);
-    w.At = c.take<float>((size_t)d.Np * d.Mk);
-    w.Akl = kl ? c.take<float>((size_t)d.Np * d.Mk) : nullptr;
-    w.Xt = c.take<float>((size_t)d.Tp * d.Mk);
-    w.H0 = with_synth ? c.take<float>((size_t)d.Tp * d.Np) : nullptr;
-    w.fb.Aw = c.take<float>(w.caps.aw);
-    w.fb.Xw = c.take<float>(w.caps.xw);
-    w.fb.Hw = c.take<float>(w.caps.hw);
-    w.fb.Pw = c.take<float>(w.caps.hw);
-    w.fb.Vpart = c.take<float>(w.caps.vpart);
-    w.fb.Vsum = c.take<float>(w.caps.vsum);
+    w.caps = WideKind<T>::caps(d.M, d.N, d.T_, n_cus);
+    w.At = c.take<T>((size_t)d.Np * d.Mk);
+    w.Akl = kl ? c.take<T>((size_t)d.Np * d.Mk) : nullptr;
+    w.Xt = c.take<T>((size_t)d.Tp * d.Mk);
+    w.H0 = with_synth ? c.take<T>((size_t)d.Tp * d.Np) : nullptr;
+    w.fb.Aw = c.take<T>(w.caps.aw);
+    w.fb.Xw = c.take<T>(w.caps.xw);
+    w.fb.Hw = c.take<T>(w.caps.hw);
+    w.fb.Pw = c.take<T>(w.caps.hw);
+    w.fb.Vpart = c.take<T>(w.caps.vpart);
+    w.fb.Vsum = c.take<T>(w.caps.vsum);
     w.fb.ctl = c.take<unsigned>(w.caps.ctl);
     w.err2 = c.take<double>(d.Tp);
     w.u.frame_utt = c.take<int>(d.Tp);
@@ -484,31 +515,37 @@ WideWs carve_wide(void* base, const Dims& d, int n_slots, int n_cus, bool with_s
     w.bytes = (c.off + 255) & ~size_t(255);
     return w;
 }
-// Batches of fewer than ~300 frame tiles (about seven utterances) stay on the two-contraction path: with so few
-// frames the exemplar ranges of a frame group must be many (23 for one utterance) and the dependency hops of the
-// task queue (publish, reduce, gather: measured ~40 us per iteration) outweigh what the fusion saves - 90 against
-// 47 us per iteration for one utterance, 139 / 132 for four, 226 / 241 for eight, 334 / 457 for sixteen
-// (profiles/r03_wide_tuning.md).  The tuning bits (ranges, wavefronts) force the fused kernel at any size.
+// float32 (k_fused_wide): batches of fewer than ~300 frame tiles (about seven utterances) stay on the two-contraction
+// path: with so few frames the exemplar ranges of a frame group must be many (23 for one utterance) and the
+// dependency hops of the task queue (publish, reduce, gather: measured ~40 us per iteration) outweigh what the
+// fusion saves - 90 against 47 us per iteration for one utterance, 139 / 132 for four, 226 / 241 for eight,
+// 334 / 457 for sixteen (profiles/r03_wide_tuning.md).  The tuning bits (ranges, wavefronts) force the fused
+// kernel at any size.  float64 (k_fused_wide64): a task is long (64-cycle MFMAs), the hops are a few per cent of it.
 constexpr int WIDE_MIN_TILES = 300;
-bool use_wide(int M, int N, int T_, int dtype, int algo, int reserved) {
-    if ((reserved & EVC_FLAG_NO_FUSED) || !wide_supported(M, N, T_, dtype, algo)) return false;
+constexpr bool WIDE64_DEFAULT = false;      // (until it beats the two-contraction path: forced by the tuning bits)
+bool use_wide(int M, int N, int T_, int dtype, int algo, int loss, int reserved) {
+    if (reserved & EVC_FLAG_NO_FUSED) return false;
     const bool forced = ((reserved >> 8) & 0xff) != 0 || ((reserved >> 16) & 0xf) != 0;
+    if (dtype == EVC_F64) return wide64_supported(M, N, T_, dtype, algo, loss) && (forced || WIDE64_DEFAULT);
+    if (!wide_supported(M, N, T_, dtype, algo)) return false;
     return forced || (T_ + 15) / 16 >= WIDE_MIN_TILES;
 }
 
-int solve_wide(const float* A, int lda, const float* X, int ldx, float* H, int ldh, int M, int N, int T_,
+template <typename T>
+int solve_wide(const T* A, int lda, const T* X, int ldx, T* H, int ldh, int M, int N, int T_,
                const int* utt_offsets, int n_utt, const evc_solve_opts& o, void* ws, size_t ws_bytes,
                int* n_iter_out, double* err_out, const SynthArgs* y, hipStream_t s, evc_solve_info* inf) {
-    const Dims d = make_dims(4, M, N, T_, n_utt, y ? y->Mb : 0);
+    typedef WideKind<T> K;
+    const Dims d = make_dims((int)sizeof(T), M, N, T_, n_utt, y ? y->Mb : 0);
     const int n_slots = n_slots_for(o.iters, o.check_every);
     if (n_slots > MAX_SLOTS) return ST_UNSUPPORTED;
     const int n_cus = device_cus();
     const bool kl = o.loss == EVC_LOSS_KL, fm = o.layout == EVC_FRAME_MAJOR;
-    WideWs w = carve_wide(ws, d, MAX_SLOTS, n_cus, true, true);
+    WideWs<T> w = carve_wide<T>(ws, d, MAX_SLOTS, n_cus, true, sizeof(T) == 4);
     if (w.bytes > ws_bytes) return ST_WORKSPACE;
     w.u.n_slots = n_slots;
     // tuning / tests: reserved bits 8..15 = exemplar ranges per frame group, bits 16..19 = wavefronts per workgroup
-    const WideLayout fl = wide_layout(M, N, T_, n_cus, (o.reserved >> 8) & 0xff, (o.reserved >> 16) & 0xf);
+    const typename K::Layout fl = K::layout(M, N, T_, n_cus, (o.reserved >> 8) & 0xff, (o.reserved >> 16) & 0xf);
     if (!wide_fits(fl, w.caps)) return ST_WORKSPACE;
 
     if (utt_offsets)
@@ -518,8 +555,8 @@ int solve_wide(const float* A, int lda, const float* X, int ldx, float* H, int l
     HIP_TRY(utt_setup(w.u, n_utt, T_, d.Tp, o.iters, s));
     SynthArgs ydict;
     if (o.dict) {                 // the block images (and B) come from the prepared dictionary
-        const DictArrays<float> ext = dict_arrays<float>(o.dict, 0);
-        w.fb.Aw = ext.Aw;
+        const DictArrays<T> ext = dict_arrays<T>(o.dict, 0);
+        w.fb.Aw = K::image(ext);
         if (y && o.dict->Mb > 0) {
             ydict = *y;
             ydict.B = ext.Bc; ydict.ldb = o.dict->Mb; ydict.b_rows = 1;
@@ -527,12 +564,12 @@ int solve_wide(const float* A, int lda, const float* X, int ldx, float* H, int l
         }
         inf->prepared = 1;
     } else {
-        HIP_TRY(copy2d<float>(A, lda, N, M, fm ? 0 : 1, w.At, d.Mk, d.Np, d.Mk, 0, s));
-        if (kl) HIP_TRY(kl_scale_dict<float>(w.At, d.Mk, M, d.Np, o.eps, w.Akl, s));
+        HIP_TRY(copy2d<T>(A, lda, N, M, fm ? 0 : 1, w.At, d.Mk, d.Np, d.Mk, 0, s));
+        if (kl) HIP_TRY(kl_scale_dict<T>(w.At, d.Mk, M, d.Np, o.eps, w.Akl, s));
         HIP_TRY(wide_pack_dict(fl, kl ? w.Akl : w.At, w.At, d.Mk, d.Np, w.fb.Aw, s));
     }
-    HIP_TRY(copy2d<float>(X, ldx, T_, M, fm ? 0 : 1, w.Xt, d.Mk, d.Tp, d.Mk, 0, s));
-    if (o.init_mode == EVC_INIT_SKLEARN) HIP_TRY(utt_sklearn_h0<float>(w.Xt, d.Mk, M, N, w.u, n_utt, s));
+    HIP_TRY(copy2d<T>(X, ldx, T_, M, fm ? 0 : 1, w.Xt, d.Mk, d.Tp, d.Mk, 0, s));
+    if (o.init_mode == EVC_INIT_SKLEARN) HIP_TRY(utt_sklearn_h0<T>(w.Xt, d.Mk, M, N, w.u, n_utt, s));
     else if (o.init_mode == EVC_INIT_CONST) HIP_TRY(utt_const_h0(w.u, n_utt, o.init_value, s));
     HIP_TRY(wide_pack_x(fl, w.Xt, d.Mk, d.Tp, w.fb.Xw, s));
     const int init_const = o.init_mode == EVC_INIT_GIVEN ? 0 : 1;
@@ -540,7 +577,7 @@ int solve_wide(const float* A, int lda, const float* X, int ldx, float* H, int l
     HIP_TRY(wide_begin(fl, w.fb, s));
     const int mode = kl ? 100 : o.eps_mode;
 
-    inf->kernel = EVC_KERNEL_FUSED_WIDE;
+    inf->kernel = K::kernel;
     inf->members = fl.c;
     inf->exchange = fl.c > 1 ? 1 : 0;
     int next_it = 0;                 // first iteration not yet run (0 = the pass that forms P and V = A H0)
@@ -585,7 +622,7 @@ int solve_wide(const float* A, int lda, const float* X, int ldx, float* H, int l
     if (H) HIP_TRY(wide_export_h(fl, w.fb.Hw, H, ldh, fm ? 1 : 0, T_, N, abort, s));
     if (y) {
         HIP_TRY(wide_export_h(fl, w.fb.Hw, w.H0, d.Np, 1, T_, N, abort, s));
-        int st = synth_rows<float>(w.H0, d.Np, *y, N, T_, fm, s);
+        int st = synth_rows<T>(w.H0, d.Np, *y, N, T_, fm, s);
         if (st) return st;
     }
     return copy_back(w.u, n_utt, n_slots, n_iter_out, err_out, s);
@@ -819,12 +856,20 @@ static size_t f32_staging_bytes(int M, int Mb, int N, int T) {
 size_t evc_workspace_bytes(int M, int Mb, int N, int T, int n_utt, int dtype, int algo) {
     if (M < 0 || Mb < 0 || N < 0 || T < 0 || n_utt < 1) return 0;
     if (algo < EVC_ALGO_GRAM || algo > EVC_ALGO_AUTO) return 0;
-    if (dtype == EVC_F64) return workspace_typed<double>(M, Mb, N, T, n_utt, algo);
+    if (dtype == EVC_F64) {
+        size_t b = workspace_typed<double>(M, Mb, N, T, n_utt, algo);
+        if (wide64_supported(M, N, T, dtype, algo == EVC_ALGO_AUTO ? EVC_ALGO_FACTORED : algo, EVC_LOSS_FROBENIUS)) {
+            const Dims d = make_dims(8, M, N, T, n_utt, Mb);
+            const size_t wb = carve_wide<double>(nullptr, d, MAX_SLOTS, device_cus(), true, false).bytes;
+            if (wb > b) b = wb;
+        }
+        return b;
+    }
     if (dtype == EVC_F32) {
         size_t b = workspace_typed<float>(M, Mb, N, T, n_utt, algo);
         if (wide_supported(M, N, T, dtype, algo == EVC_ALGO_AUTO ? EVC_ALGO_FACTORED : algo)) {
             const Dims d = make_dims(4, M, N, T, n_utt, Mb);
-            const size_t wb = carve_wide(nullptr, d, MAX_SLOTS, device_cus(), true, true).bytes;
+            const size_t wb = carve_wide<float>(nullptr, d, MAX_SLOTS, device_cus(), true, true).bytes;
             if (wb > b) b = wb;
         }
         if (f32_rides_f64(M, N, T, algo, 0)) {
@@ -989,14 +1034,19 @@ static int solve_checked(const void* A, int lda, const void* X, int ldx, void* H
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     evc_solve_info inf{};
     int st;
-    if (o.dtype == EVC_F64)
+    const int algo_eff = o.algo == EVC_ALGO_AUTO ? EVC_ALGO_FACTORED : o.algo;
+    if (o.dtype == EVC_F64 && use_wide(M, N, T, o.dtype, algo_eff, o.loss, o.reserved))
+        st = solve_wide<double>(static_cast<const double*>(A), lda, static_cast<const double*>(X), ldx,
+                                static_cast<double*>(H), ldh, M, N, T, utt_offsets, n_utt, o, workspace, workspace_bytes,
+                                n_iter_out, err_out, y, s, &inf);
+    else if (o.dtype == EVC_F64)
         st = solve_typed<double>(A, lda, X, ldx, H, ldh, M, N, T, utt_offsets, n_utt, o, workspace,
                                  workspace_bytes, n_iter_out, err_out, y, s, &inf);
     else if (f32_rides_f64(M, N, T, o.algo, o.reserved))
         st = solve_f32_on_f64(A, lda, X, ldx, H, ldh, M, N, T, utt_offsets, n_utt, o, workspace, workspace_bytes,
                               n_iter_out, err_out, y, s, &inf);
-    else if (use_wide(M, N, T, o.dtype, o.algo == EVC_ALGO_AUTO ? EVC_ALGO_FACTORED : o.algo, o.reserved))
-        st = solve_wide(static_cast<const float*>(A), lda, static_cast<const float*>(X), ldx, static_cast<float*>(H),
+    else if (use_wide(M, N, T, o.dtype, algo_eff, o.loss, o.reserved))
+        st = solve_wide<float>(static_cast<const float*>(A), lda, static_cast<const float*>(X), ldx, static_cast<float*>(H),
                         ldh, M, N, T, utt_offsets, n_utt, o, workspace, workspace_bytes, n_iter_out, err_out, y, s, &inf);
     else
         st = solve_typed<float>(A, lda, X, ldx, H, ldh, M, N, T, utt_offsets, n_utt, o, workspace,

@@ -246,6 +246,40 @@ hipError_t wide_iterate(const WideLayout& f, const WideBuffers& b, const UttStat
 hipError_t wide_err2(const WideLayout& f, const WideBuffers& b, const UttState& u, int N, int T_, int it, int kl,
                      double eps, double* err2, hipStream_t s);
 
+// ----- evc_wide64.hip -----
+// The same task queue for wide float64 spectra (208 < M <= 576, Frobenius): k_fused_wide64; a workgroup of four
+// wavefronts owns 32 frames, the bins are split over its wavefronts.
+struct Wide64Layout {
+    int TPW;             // bin tiles of 16 per wavefront (template instance: 64 TPW >= M)
+    int NB;              // exemplar blocks of 16
+    int TT, G;           // frame tiles, frame groups of 2 tiles
+    int c, rmode;        // exemplar ranges per group; 1: a reduce task sums the partial V' (c > 4)
+    size_t aw, xw, hw, vpart, vsum;      // element counts (Pw has hw elements)
+};
+struct Wide64Buffers {
+    double *Aw, *Xw, *Hw, *Pw, *Vpart, *Vsum;
+    unsigned* ctl;       // [4 + 2 G]: ticket, abort flag, -, -, done[G], done_r[G]
+};
+struct Wide64Caps { size_t aw, xw, hw, vpart, vsum, ctl; int c_cap; };
+bool wide64_supported(int M, int N, int T_, int dtype, int algo, int loss);
+Wide64Layout wide64_layout(int M, int N, int T_, int n_cus, int c_req);
+size_t wide_ctl_words(const Wide64Layout& f);
+Wide64Caps wide64_caps(int M, int N, int T_, int n_cus);
+bool wide_fits(const Wide64Layout& f, const Wide64Caps& k);
+// (the second dictionary pointer, the KL-scaled rows of the float32 kernel, is unused: Frobenius only)
+hipError_t wide_pack_dict(const Wide64Layout& f, const double* At, const double* unused, int ld, int n_rows, double* Aw,
+                          hipStream_t s);
+hipError_t wide_pack_x(const Wide64Layout& f, const double* Xt, int ld, int rows, double* Xw, hipStream_t s);
+hipError_t wide_import_h(const Wide64Layout& f, double* Hw, const double* H, long ldh, int frame_major, int T_, int N,
+                           hipStream_t s);
+hipError_t wide_export_h(const Wide64Layout& f, const double* Hw, double* H, long ldh, int frame_major, int T_, int N,
+                           const int* abort, hipStream_t s);
+hipError_t wide_begin(const Wide64Layout& f, const Wide64Buffers& b, hipStream_t s);
+hipError_t wide_iterate(const Wide64Layout& f, const Wide64Buffers& b, const UttState& u, int N, int T_, int it_begin,
+                          int it_end, int mode, double eps, double l1, int init_const, int n_cus, hipStream_t s);
+hipError_t wide_err2(const Wide64Layout& f, const Wide64Buffers& b, const UttState& u, int N, int T_, int it, int kl,
+                     double eps, double* err2, hipStream_t s);
+
 // ----- evc_gl.hip -----
 size_t gl_workspace_bytes(long T_total, int n_utt, int F, int hop, int iters);
 int stft_frames(long L, int hop, bool center, int F);

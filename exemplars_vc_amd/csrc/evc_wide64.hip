@@ -1,0 +1,646 @@
+// k_fused_wide64: the fused FACTORED multiplicative update for wide float64 spectra (208 < M <= 576 bins: the
+// 513-bin STFT magnitudes of BASELINE C3 / C5_513; 04_align_n_nmf.py:315-326 with fft_size 1024).
+//
+//   per iteration and frame:  D = A^T V (+ l1, + eps)      V = A H of the previous iteration
+//                             H' = H (.) P (/) guard(D)     P = A^T X, formed once
+//                             V' = A H'
+//
+// Same task queue as k_fused_wide (evc_wide.hip: tickets in iteration-major order, per-group counters, partial V'
+// published per exemplar range, reduce tasks when the ranges are many, sc1 hand-off); what differs is who holds
+// what, because V and V' of 16 frames at M = 513 are 528 registers per lane:
+//
+// * A WORKGROUP (4 wavefronts, one per SIMD, 512 registers each) owns 32 frames = 2 frame tiles.  The bins are split
+//   over its wavefronts: wavefront w holds bin tiles 4 k + w, k < TPW, of V and of V' for BOTH frame tiles (2 x TPW
+//   accumulator tiles each).  For the 16x16x4 f64 MFMA the accumulator layout (lane = (q, frame), register r <->
+//   row q + 4 r) is the B-operand layout of k-step r (rows 4 r + q): V' feeds the next D product and D / H' feed
+//   V' += A_j H'_j without a shuffle, as in the float32 kernel.
+// * D = A_j^T V needs all bins: every wavefront multiplies its own bins (2 TPW k-steps of 4 per frame tile), the four
+//   partial 16 x 16 tiles meet in LDS (16 KiB), and wavefront w reduces and updates ONE QUARTER of the two H tiles
+//   (frame tile w / 2, register pair w % 2: it alone loads that quarter of H and P and stores that quarter of H'),
+//   the four quarters of H' meet in LDS again (4 KiB).  Two LDS-only barriers per block, no global drain.
+// * The dictionary goes global -> registers: the A-operand fragments of a wavefront's own bins are private to it (its
+//   three neighbours hold other bins), so there is nothing to share through LDS; one 16-byte load per lane feeds two
+//   k-steps x two frame tiles = four 64-cycle MFMAs, and a ring of TPW loads (half a product) is in flight.
+// * The products are software-pipelined across blocks: step i runs D of block i, then V' of block i - 1 - the
+//   partial D tiles travel through LDS, are reduced and turned into H' while V' of the previous block occupies the
+//   matrix pipe.
+#include "evc_internal.h"
+
+#include <type_traits>
+
+namespace evc {
+
+typedef unsigned w64_u32x4 __attribute__((ext_vector_type(4)));
+typedef double w64_d2 __attribute__((ext_vector_type(2)));
+
+constexpr long W64_SPIN_LIMIT = 1L << 25;
+
+struct Wide64Args {
+    const double* Aw;        // [NB][2][4][TPW][2][64][2]   per exemplar block: D-operand image, then V'-operand image
+    const double* Xw;        // [G][4][2][TPW][2][64][2]    frames in the V chunk layout
+    double* Hw;              // [2 G][NB][2][64][2]         activations, quarter-major accumulator order
+    double* Pw;              // the same layout: numerators A^T X
+    double* Vpart;           // [2][G][c][4][2][TPW][2][64][2]
+    double* Vsum;            // [2][G][4][2][TPW][2][64][2]   (reduce mode)
+    unsigned* ticket;
+    unsigned* done;          // [G]
+    unsigned* done_r;        // [G]
+    int* abort;
+    const int* frame_utt;
+    const int* active;
+    const double* h0;
+    int NB, TT, G, c, rmode;
+    int it_begin, it_end;
+    int N, T_;
+    int mode;                // EVC_EPS_*
+    double eps, l1;
+    int init_const;
+};
+
+__device__ __forceinline__ w64_d2 ld2_sc1(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(w64_d2, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 16));
+}
+__device__ __forceinline__ w64_d2 ld2(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(w64_d2, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+}
+__device__ __forceinline__ void st2_sc1(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff, w64_d2 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(w64_u32x4, v), rs, voff, soff, 16);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc64(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+// workgroup barrier that orders LDS traffic only (the global loads in flight stay in flight)
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+#ifdef EVC_WIDE_STAMP
+__device__ unsigned long long* evc_wide64_dbg = nullptr;        // [tasks of the launch][8]
+#define W64STAMP(k) do { if (tid == 0 && evc_wide64_dbg) evc_wide64_dbg[(size_t)tk * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define W64NOTE(k, v) do { if (tid == 0 && evc_wide64_dbg) evc_wide64_dbg[(size_t)tk * 8 + (k)] = (unsigned long long)(v); } while (0)
+#else
+#define W64STAMP(k)
+#define W64NOTE(k, v)
+#endif
+
+template <int TPW>
+__global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
+    constexpr int NL = 2 * TPW;                       // 16-byte fragment loads per product and wavefront
+    constexpr int KH = (TPW + 1) / 2;                 // bin tiles of the V' product that run before the first barrier
+    constexpr unsigned WCH = 2u * TPW * 2048u;        // bytes of a wavefront's V chunk (2 frame tiles x TPW tiles x 2 KiB)
+    constexpr unsigned GCH = 4u * WCH;                // ... of a frame group's
+    constexpr unsigned IMGW = NL * 1024u;             // bytes of one (block, product, wavefront) image
+    constexpr int RING = TPW;                         // fragment loads in flight (half a product: 2 TPW x 4 MFMAs)
+    constexpr unsigned OOB = 0xFFFF0000u;             // a buffer offset beyond every resource: the load returns zeros
+    __shared__ w64_d2 s_d[4][2][2][64];               // partial D: [source wavefront][frame tile][register pair][lane]
+    __shared__ w64_d2 s_h[2][2][64];                  // H' of the block: [frame tile][register pair][lane]
+    __shared__ volatile unsigned s_ctl[4];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int q = lane >> 4, i16 = lane & 15;
+    const int ftq = w >> 1, xq = w & 1;               // the quarter this wavefront reduces and updates
+    const unsigned GC = (unsigned)(a.G * a.c);
+    const unsigned per_it = a.rmode ? 2u * GC : GC;
+    const unsigned total = per_it * (unsigned)(a.it_end - a.it_begin);
+    const unsigned c = (unsigned)a.c;
+    const unsigned lane16 = (unsigned)lane * 16u;
+
+    unsigned nxt = 0;
+    if (tid == 0) {
+        nxt = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_ctl[0] = nxt;
+        s_ctl[1] = 1u;
+    }
+    __syncthreads();
+
+    auto wait_for = [&](const unsigned* ctr, unsigned need) -> bool {
+        if (tid == 0) {
+            unsigned ok = 1u;
+            long spins = 0;
+            while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                __builtin_amdgcn_s_sleep(2);
+                ++spins;
+                if ((spins & 63) == 0 && __hip_atomic_load(a.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                    ok = 0u;
+                    break;
+                }
+                if (spins > W64_SPIN_LIMIT) {
+                    __hip_atomic_store(a.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0u;
+                    break;
+                }
+            }
+            s_ctl[1] = ok;
+        }
+        __syncthreads();
+        return s_ctl[1] != 0u;
+    };
+
+    const __amdgpu_buffer_rsrc_t ra = rsrc64(a.Aw, (unsigned)a.NB * 8u * IMGW);
+
+    for (;;) {
+        const unsigned tk = __builtin_amdgcn_readfirstlane(s_ctl[0]);
+        if (tk >= total) break;
+        __syncthreads();
+        if (tid == 0) nxt = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned itl = tk / per_it, rem = tk - itl * per_it;
+        const int it = a.it_begin + (int)itl;
+        const bool reduce = rem >= GC;
+        const unsigned idx = reduce ? rem - GC : rem;
+        const int g = (int)(idx / c), e = (int)(idx - (unsigned)g * c);
+        const unsigned par = (unsigned)(it & 1);
+        W64STAMP(0);
+        W64NOTE(6, (reduce ? 1u : 0u) | ((unsigned)blockIdx.x << 8));
+        W64NOTE(7, ((unsigned long long)it << 32) | (unsigned)(g * 256 + e));
+
+        if (reduce) {
+            // ---- reduce task: slice e of the group's V' = sum over the c ranges, in range order ----
+            if (!wait_for(a.done + g, c * (unsigned)(it + 1))) break;
+            W64STAMP(1);
+            constexpr unsigned U = GCH / 16u;                     // 16-byte units of a group's partial
+            const unsigned lo = (unsigned)((unsigned long)e * U / c), hi = (unsigned)((unsigned long)(e + 1) * U / c);
+            const __amdgpu_buffer_rsrc_t rin = rsrc64(a.Vpart + ((size_t)(par * a.G + g) * c) * (GCH / 8), c * GCH);
+            const __amdgpu_buffer_rsrc_t rout = rsrc64(a.Vsum + (size_t)(par * a.G + g) * (GCH / 8), GCH);
+            for (unsigned un = lo + tid; un < hi; un += 256) {
+                w64_d2 acc = w64_d2{0, 0};
+                for (unsigned m0 = 0; m0 < c; m0 += 16) {
+                    w64_d2 v[16];
+#pragma unroll
+                    for (unsigned k = 0; k < 16; ++k) {
+                        const unsigned m = m0 + k < c ? m0 + k : c - 1;
+                        v[k] = ld2_sc1(rin, un * 16u, m * GCH);
+                    }
+#pragma unroll
+                    for (unsigned k = 0; k < 16; ++k)
+                        if (m0 + k < c) acc = (m0 + k) ? acc + v[k] : v[k];
+                }
+                st2_sc1(rout, un * 16u, 0, acc);
+            }
+            W64STAMP(3);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            W64STAMP(4);
+            if (tid == 0) {
+                __hip_atomic_fetch_add(a.done_r + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_ctl[0] = nxt;
+            }
+            __syncthreads();
+            W64STAMP(5);
+            continue;
+        }
+
+        // ---- sweep task (iteration it, frame group g, exemplar range e) ----
+        const int j0 = (int)((long)e * a.NB / a.c), j1 = (int)((long)(e + 1) * a.NB / a.c), nb = j1 - j0;
+        // segment s of the fragment stream: s = 2 i is the D image of block j0 + i, s = 2 i + 1 the V' image of block
+        // j0 + i - 1 (none for i = 0); load l of it.  Beyond the range: an out-of-bounds offset (zeros, no traffic).
+        unsigned seg_v = 0, seg_s = 0;                 // offsets of the segment the ring is being refilled from
+        auto seg_set = [&](int s) {
+            const int i = s >> 1, p = s & 1;
+            const bool valid = p ? (i >= 1 && i <= nb) : (i < nb);
+            seg_s = valid ? ((unsigned)(j0 + i - p) * 8u + (unsigned)p * 4u + (unsigned)w) * IMGW : 0u;
+            seg_v = valid ? lane16 : OOB;
+        };
+        auto seg_load = [&](int l) -> w64_d2 { return ld2(ra, seg_v, seg_s + (unsigned)l * 1024u); };
+        w64_d2 ring[RING];
+        seg_set(0);
+#pragma unroll
+        for (int l = 0; l < RING; ++l) ring[l] = seg_load(l);      // the dictionary does not depend on anybody
+        if (it > 0 && !wait_for(a.rmode ? a.done_r + g : a.done + g, c * (unsigned)it)) break;
+        W64STAMP(1);
+
+        // V of this wavefront's bins, both frame tiles
+        f64x4 Vin[2][TPW], Vn[2][TPW];
+        {
+            const double* src;
+            unsigned nsum = 1, stride = 0;
+            if (it == 0) {
+                src = a.Xw + (size_t)g * (GCH / 8);
+            } else if (a.rmode) {
+                src = a.Vsum + (size_t)((par ^ 1u) * a.G + g) * (GCH / 8);
+            } else {
+                src = a.Vpart + ((size_t)((par ^ 1u) * a.G + g) * c) * (GCH / 8);
+                nsum = c;
+                stride = GCH;
+            }
+            const __amdgpu_buffer_rsrc_t rv = rsrc64(src, nsum * GCH);
+            const unsigned wbase = (unsigned)w * WCH;
+            for (unsigned m = 0; m < nsum; ++m) {
+#pragma unroll
+                for (int f = 0; f < 2; ++f)
+#pragma unroll
+                    for (int k = 0; k < TPW; ++k) {
+                        const unsigned o = wbase + (unsigned)((f * TPW + k) * 2) * 1024u + lane16;
+                        const w64_d2 v0 = ld2_sc1(rv, o, m * stride), v1 = ld2_sc1(rv, o + 1024u, m * stride);
+                        const f64x4 v = f64x4{v0[0], v0[1], v1[0], v1[1]};
+                        Vin[f][k] = m ? Vin[f][k] + v : v;
+                    }
+            }
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int k = 0; k < TPW; ++k) Vn[f][k] = f64x4{0, 0, 0, 0};
+        }
+        // the quarter of H / P this wavefront owns: frame tile 2 g + ftq, registers 2 xq, 2 xq + 1
+        const int ft = 2 * g + ftq;
+        bool live = false;
+        double h0v = 0.0;
+        {
+            const int t = ft * 16 + i16;
+            if (t < a.T_) {
+                const int ut = a.frame_utt[t];
+                if (ut >= 0) {
+                    live = a.active[ut] != 0;
+                    h0v = a.h0[ut];
+                }
+            }
+        }
+        const __amdgpu_buffer_rsrc_t rh = rsrc64(a.Hw + (size_t)ft * a.NB * 256, (unsigned)a.NB * 2048u);
+        const __amdgpu_buffer_rsrc_t rp = rsrc64(a.Pw + (size_t)ft * a.NB * 256, (unsigned)a.NB * 2048u);
+        const unsigned qoff = (unsigned)xq * 1024u + lane16;          // within a 2 KiB tile
+        const bool load_h = it > 0 || !a.init_const, load_p = it > 0;
+        const int n_edge = (a.N & 15) ? a.NB - 1 : -1;
+        w64_d2 hC = w64_d2{0, 0}, pC = hC, hN = hC, pN = hC;
+        if (nb > 0) {
+            if (load_h) hC = ld2_sc1(rh, qoff, (unsigned)j0 * 2048u);
+            if (load_p) pC = ld2_sc1(rp, qoff, (unsigned)j0 * 2048u);
+        }
+        f64x4 hf[2];                                   // H' of the previous block, both frame tiles (B operand of V')
+        hf[0] = f64x4{0, 0, 0, 0};
+        hf[1] = hf[0];
+        W64STAMP(2);
+        // loads [l0, l1) of the V' product (when `run`: the first step has no previous block); the ring refills with
+        // the rest of this image, then with the first loads of segment s_next
+        auto product_v = [&](auto l0c, auto l1c, bool run, int s_next) {
+            constexpr int l0 = decltype(l0c)::value, l1 = decltype(l1c)::value;
+            if (run) {
+#pragma unroll
+                for (int l = l0; l < l1; ++l) {
+                    const int k = l >> 1, h = l & 1;
+                    const w64_d2 fr = ring[l % RING];
+                    Vn[0][k] = Mma<double>::mma(fr[0], hf[0][2 * h], Vn[0][k]);
+                    Vn[1][k] = Mma<double>::mma(fr[0], hf[1][2 * h], Vn[1][k]);
+                    Vn[0][k] = Mma<double>::mma(fr[1], hf[0][2 * h + 1], Vn[0][k]);
+                    Vn[1][k] = Mma<double>::mma(fr[1], hf[1][2 * h + 1], Vn[1][k]);
+                    if (l + RING == NL) seg_set(s_next);
+                    ring[l % RING] = seg_load((l + RING) % NL);
+                }
+            } else if (l1 == NL) {
+                seg_set(s_next);
+#pragma unroll
+                for (int l = 0; l < RING; ++l) ring[l] = seg_load(l);
+            }
+        };
+
+#pragma clang loop unroll(disable)
+        for (int i = 0; i <= nb; ++i) {
+            const int jb = j0 + i;
+            const bool has_d = i < nb, has_v = i >= 1;
+            if (i + 1 < nb) {
+                if (load_h) hN = ld2_sc1(rh, qoff, (unsigned)(jb + 1) * 2048u);
+                if (load_p) pN = ld2_sc1(rp, qoff, (unsigned)(jb + 1) * 2048u);
+            }
+            // ---- D partial of block jb over this wavefront's bins; the ring refills with the V' image of block jb - 1
+            // (refill l of a product's loop: load l + RING of the same segment, then the first RING loads of the next)
+            f64x4 da[2];
+            da[0] = f64x4{0, 0, 0, 0};
+            da[1] = da[0];
+            if (has_d) {
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    const int k = l >> 1, h = l & 1;
+                    const w64_d2 fr = ring[l % RING];
+                    da[0] = Mma<double>::mma(fr[0], Vin[0][k][2 * h], da[0]);
+                    da[1] = Mma<double>::mma(fr[0], Vin[1][k][2 * h], da[1]);
+                    da[0] = Mma<double>::mma(fr[1], Vin[0][k][2 * h + 1], da[0]);
+                    da[1] = Mma<double>::mma(fr[1], Vin[1][k][2 * h + 1], da[1]);
+                    if (l + RING == NL) seg_set(2 * i + 1);
+                    ring[l % RING] = seg_load((l + RING) % NL);
+                }
+            } else {
+                seg_set(2 * i + 1);
+#pragma unroll
+                for (int l = 0; l < RING; ++l) ring[l] = seg_load(l);
+            }
+            if (has_d) {
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    const f64x4 d = da[f];
+                    s_d[w][f][0][lane] = w64_d2{d[0], d[1]};
+                    s_d[w][f][1][lane] = w64_d2{d[2], d[3]};
+                }
+            }
+            // ---- V' += A_(jb-1) H'_(jb-1), first half of the bin tiles; the ring refills with the D image of block jb + 1
+            product_v(std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * KH>{}, has_v, 2 * i + 2);
+            lds_barrier();                              // the four partial D tiles are in LDS
+            if (has_d) {
+                // reduce this wavefront's quarter in wavefront order, update it
+                w64_d2 dq = s_d[0][ftq][xq][lane];
+                dq += s_d[1][ftq][xq][lane];
+                dq += s_d[2][ftq][xq][lane];
+                dq += s_d[3][ftq][xq][lane];
+                w64_d2 hn;
+                if (it == 0) {
+                    if (a.init_const) {
+#pragma unroll
+                        for (int y = 0; y < 2; ++y) hn[y] = (jb * 16 + q + 4 * (2 * xq + y) < a.N) ? h0v : 0.0;
+                        st2_sc1(rh, qoff, (unsigned)jb * 2048u, hn);
+                    } else {
+                        hn = hC;
+                    }
+                    st2_sc1(rp, qoff, (unsigned)jb * 2048u, dq);
+                } else {
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) hn[y] = mu_update<double>(hC[y], pC[y], dq[y], a.mode, a.eps, a.l1);
+                    if (jb == n_edge) {
+#pragma unroll
+                        for (int y = 0; y < 2; ++y) hn[y] = (jb * 16 + q + 4 * (2 * xq + y) < a.N) ? hn[y] : 0.0;
+                    }
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) hn[y] = live ? hn[y] : hC[y];
+                    st2_sc1(rh, qoff, (unsigned)jb * 2048u, hn);
+                }
+                s_h[ftq][xq][lane] = hn;
+            }
+            // ---- the second half of V' of block jb - 1
+            product_v(std::integral_constant<int, 2 * KH>{}, std::integral_constant<int, NL>{}, has_v, 2 * i + 2);
+            lds_barrier();                              // the four quarters of H' are in LDS
+            if (has_d) {
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    const w64_d2 v0 = s_h[f][0][lane], v1 = s_h[f][1][lane];
+                    hf[f] = f64x4{v0[0], v0[1], v1[0], v1[1]};
+                }
+            }
+            hC = hN;
+            pC = pN;
+        }
+
+        W64STAMP(3);
+        // publish the partial V' of this range
+        {
+            const __amdgpu_buffer_rsrc_t rv =
+                rsrc64(a.Vpart + (((size_t)(par * a.G + g) * c + e) * 4 + w) * (WCH / 8), WCH);
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int k = 0; k < TPW; ++k) {
+                    const unsigned o = (unsigned)((f * TPW + k) * 2) * 1024u + lane16;
+                    st2_sc1(rv, o, 0, w64_d2{Vn[f][k][0], Vn[f][k][1]});
+                    st2_sc1(rv, o + 1024u, 0, w64_d2{Vn[f][k][2], Vn[f][k][3]});
+                }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        W64STAMP(4);
+        if (tid == 0) {
+            __hip_atomic_fetch_add(a.done + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_ctl[0] = nxt;
+        }
+        __syncthreads();
+        W64STAMP(5);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// packing / unpacking
+// ------------------------------------------------------------------------------------------
+// Aw[jb][0][w][k][h][lane = 16 q + i][x] = A[bin 16 (4 k + w) + 4 (2 h + x) + q][exemplar 16 jb + i]       (A operand of D)
+// Aw[jb][1][w][k][h][lane = 16 q + i][x] = A[bin 16 (4 k + w) + i][exemplar 16 jb + 4 (2 h + x) + q]       (A operand of V')
+// At: exemplars as rows (n_rows x ld, zero padded), bins < ld
+__global__ __launch_bounds__(256) void k_wide64_pack_dict(const double* __restrict__ At, int ld, int n_rows, int NB,
+                                                          int TPW, double* __restrict__ Aw) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long per_block = 2L * 4 * TPW * 256;
+    if (gid >= (long)NB * per_block) return;
+    const long jb = gid / per_block;
+    int o = (int)(gid - jb * per_block);
+    const int x = o & 1, lane = (o >> 1) & 63, h = (o >> 7) & 1;
+    o >>= 8;
+    const int k = o % TPW, w = (o / TPW) & 3, p = o / (4 * TPW);
+    const int q = lane >> 4, i = lane & 15, r = 2 * h + x, u = 4 * k + w;
+    const int bin = p ? 16 * u + i : 16 * u + 4 * r + q;
+    const long n = p ? 16 * jb + 4 * r + q : 16 * jb + i;
+    Aw[gid] = (n < n_rows && bin < ld) ? At[n * ld + bin] : 0.0;
+}
+
+// Xw[g][w][f][k][h][lane = 16 q + i][x] = X[frame 16 (2 g + f) + i][bin 16 (4 k + w) + q + 4 (2 h + x)]
+__global__ __launch_bounds__(256) void k_wide64_pack_x(const double* __restrict__ Xt, int ld, int rows, long G, int TPW,
+                                                       double* __restrict__ Xw) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    const long per_group = 4L * 2 * TPW * 256;
+    if (gid >= G * per_group) return;
+    const long g = gid / per_group;
+    int o = (int)(gid - g * per_group);
+    const int x = o & 1, lane = (o >> 1) & 63, h = (o >> 7) & 1;
+    o >>= 8;
+    const int k = o % TPW, f = (o / TPW) & 1, w = o / (2 * TPW);
+    const int q = lane >> 4, i = lane & 15;
+    const long t = 16 * (2 * g + f) + i;
+    const int bin = 16 * (4 * k + w) + q + 4 * (2 * h + x);
+    Xw[gid] = (t < rows && bin < ld) ? Xt[t * ld + bin] : 0.0;
+}
+
+// Hw[ft][jb][x][lane = 16 q + i][y] <-> H[exemplar 16 jb + q + 4 (2 x + y)][frame 16 ft + i]
+template <bool IMPORT>
+__global__ __launch_bounds__(256) void k_wide64_h_io(double* __restrict__ H, long ldh, int frame_major, int T_, int N,
+                                                     w64_d2* __restrict__ Hw, long units, int NB, const int* abort) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;       // one 16-byte unit each
+    if (gid >= units) return;
+    const int lane = (int)(gid & 63), x = (int)((gid >> 6) & 1);
+    const long tile = gid >> 7, ft = tile / NB, jb = tile % NB;
+    const int q = lane >> 4, i = lane & 15;
+    const long t = 16 * ft + i;
+    if (IMPORT) {
+        w64_d2 v = w64_d2{0, 0};
+        if (t < T_) {
+#pragma unroll
+            for (int y = 0; y < 2; ++y) {
+                const long n = 16 * jb + q + 4 * (2 * x + y);
+                if (n < N) v[y] = frame_major ? H[t * ldh + n] : H[n * ldh + t];
+            }
+        }
+        Hw[gid] = v;
+    } else {
+        if (t >= T_) return;
+        w64_d2 v = Hw[gid];
+        if (abort && *abort) v = w64_d2{__builtin_nan(""), __builtin_nan("")};
+#pragma unroll
+        for (int y = 0; y < 2; ++y) {
+            const long n = 16 * jb + q + 4 * (2 * x + y);
+            if (n < N) {
+                if (frame_major) H[t * ldh + n] = v[y]; else H[n * ldh + t] = v[y];
+            }
+        }
+    }
+}
+
+// err2[t] = sum_m (X - V)^2 of frame t, V = the sum of the c partials of iteration `it` (or their reduced sum);
+// one wavefront per frame tile
+__global__ __launch_bounds__(256) void k_wide64_err2(Wide64Args a, int TPW, int it, double* __restrict__ err2) {
+    const int lane = threadIdx.x & 63;
+    const long ft = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ft >= a.TT) return;
+    const int g = (int)(ft >> 1), f = (int)(ft & 1);
+    const unsigned par = (unsigned)(it & 1);
+    const size_t wch = (size_t)2 * TPW * 128, gch = 4 * wch;          // 16-byte units
+    const w64_d2* xw = reinterpret_cast<const w64_d2*>(a.Xw) + (size_t)g * gch;
+    const w64_d2* vs = reinterpret_cast<const w64_d2*>(a.Vsum) + (size_t)(par * a.G + g) * gch;
+    const w64_d2* vp = reinterpret_cast<const w64_d2*>(a.Vpart) + (size_t)(par * a.G + g) * a.c * gch;
+    double acc = 0.0;
+    for (int w = 0; w < 4; ++w)
+        for (int kh = 0; kh < 2 * TPW; ++kh) {
+            const size_t o = (size_t)w * wch + ((size_t)f * 2 * TPW + kh) * 64 + lane;
+            w64_d2 v;
+            if (a.rmode) {
+                v = vs[o];
+            } else {
+                v = vp[o];
+                for (int m = 1; m < a.c; ++m) v += vp[(size_t)m * gch + o];
+            }
+            const w64_d2 x = xw[o];
+            acc += (x[0] - v[0]) * (x[0] - v[0]) + (x[1] - v[1]) * (x[1] - v[1]);
+        }
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
+    const long t = 16 * ft + (lane & 15);
+    if (lane < 16 && t < a.T_) err2[t] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static const int WIDE64_TPW_SET[] = {5, 7, 9};
+
+size_t wide_ctl_words(const Wide64Layout& f) { return 4 + 2 * (size_t)f.G; }
+
+bool wide64_supported(int M, int N, int T_, int dtype, int algo, int loss) {
+    return dtype == EVC_F64 && algo == EVC_ALGO_FACTORED && loss == EVC_LOSS_FROBENIUS && M > 208 && M <= 576 &&
+           N >= 16 && T_ >= 1;
+}
+
+Wide64Layout wide64_layout(int M, int N, int T_, int n_cus, int c_req) {
+    Wide64Layout f{};
+    const int tpw = (M + 63) / 64;
+    f.TPW = 9;
+    for (int v : WIDE64_TPW_SET)
+        if (v >= tpw) { f.TPW = v; break; }
+    f.NB = (N + 15) / 16;
+    f.TT = (T_ + 15) / 16;
+    f.G = (f.TT + 1) / 2;
+    if (n_cus <= 0) n_cus = 256;
+    int c = c_req > 0 ? c_req : (f.G >= n_cus ? 1 : (f.G * 4 >= n_cus ? (n_cus + f.G - 1) / f.G : n_cus / f.G));
+    const int cmax = f.NB / 2 > 0 ? f.NB / 2 : 1;
+    if (c > cmax) c = cmax;
+    if (c > 64) c = 64;
+    f.c = c;
+    f.rmode = c > 4 ? 1 : 0;
+    const size_t gch = (size_t)4 * 2 * f.TPW * 256;       // doubles per group chunk
+    f.aw = (size_t)f.NB * 2 * 4 * f.TPW * 256;
+    f.xw = (size_t)f.G * gch;
+    f.hw = (size_t)f.G * 2 * f.NB * 256;
+    f.vpart = 2 * (size_t)f.G * f.c * gch;
+    f.vsum = 2 * (size_t)f.G * gch;
+    return f;
+}
+
+Wide64Caps wide64_caps(int M, int N, int T_, int n_cus) {
+    const Wide64Layout a = wide64_layout(M, N, T_, n_cus, 0);
+    Wide64Caps k{};
+    int c_cap = a.c;
+    if (a.TT <= 4096 && c_cap < 8) c_cap = 8;
+    if (a.TT <= 256) c_cap = 64;
+    const int cmax = a.NB / 2 > 0 ? a.NB / 2 : 1;
+    if (c_cap > cmax) c_cap = cmax;
+    k.c_cap = c_cap;
+    const size_t gch = (size_t)4 * 2 * a.TPW * 256;
+    k.aw = a.aw;
+    k.xw = a.xw;
+    k.hw = a.hw;
+    k.vpart = 2 * (size_t)a.G * c_cap * gch;
+    k.vsum = a.vsum;
+    k.ctl = wide_ctl_words(a);
+    return k;
+}
+bool wide_fits(const Wide64Layout& f, const Wide64Caps& k) {
+    return f.aw <= k.aw && f.xw <= k.xw && f.hw <= k.hw && f.vpart <= k.vpart && f.vsum <= k.vsum &&
+           wide_ctl_words(f) <= k.ctl && f.aw * 8 < 0xFF000000ull;
+}
+
+hipError_t wide_pack_dict(const Wide64Layout& f, const double* At, const double*, int ld, int n_rows, double* Aw,
+                          hipStream_t s) {
+    const long n = (long)f.aw;
+    hipLaunchKernelGGL(k_wide64_pack_dict, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, At, ld, n_rows, f.NB, f.TPW,
+                       Aw);
+    return hipGetLastError();
+}
+
+hipError_t wide_pack_x(const Wide64Layout& f, const double* Xt, int ld, int rows, double* Xw, hipStream_t s) {
+    const long n = (long)f.xw;
+    hipLaunchKernelGGL(k_wide64_pack_x, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, Xt, ld, rows, (long)f.G, f.TPW,
+                       Xw);
+    return hipGetLastError();
+}
+
+hipError_t wide_import_h(const Wide64Layout& f, double* Hw, const double* H, long ldh, int frame_major, int T_, int N,
+                           hipStream_t s) {
+    const long units = (long)f.G * 2 * f.NB * 128;
+    hipLaunchKernelGGL((k_wide64_h_io<true>), dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, const_cast<double*>(H),
+                       ldh, frame_major, T_, N, reinterpret_cast<w64_d2*>(Hw), units, f.NB, (const int*)nullptr);
+    return hipGetLastError();
+}
+
+hipError_t wide_export_h(const Wide64Layout& f, const double* Hw, double* H, long ldh, int frame_major, int T_, int N,
+                           const int* abort, hipStream_t s) {
+    const long units = (long)f.TT * f.NB * 128;
+    hipLaunchKernelGGL((k_wide64_h_io<false>), dim3((unsigned)((units + 255) / 256)), dim3(256), 0, s, H, ldh, frame_major,
+                       T_, N, reinterpret_cast<w64_d2*>(const_cast<double*>(Hw)), units, f.NB, abort);
+    return hipGetLastError();
+}
+
+static Wide64Args wide64_args(const Wide64Layout& f, const Wide64Buffers& b, const UttState& u, int N, int T_, int mode,
+                              double eps, double l1, int init_const) {
+    Wide64Args a{};
+    a.Aw = b.Aw; a.Xw = b.Xw; a.Hw = b.Hw; a.Pw = b.Pw; a.Vpart = b.Vpart; a.Vsum = b.Vsum;
+    a.ticket = b.ctl; a.done = b.ctl + 4; a.done_r = b.ctl + 4 + f.G; a.abort = reinterpret_cast<int*>(b.ctl + 1);
+    a.frame_utt = u.frame_utt; a.active = u.active; a.h0 = u.h0;
+    a.NB = f.NB; a.TT = f.TT; a.G = f.G; a.c = f.c; a.rmode = f.rmode;
+    a.N = N; a.T_ = T_; a.mode = mode; a.eps = eps; a.l1 = l1; a.init_const = init_const;
+    return a;
+}
+
+hipError_t wide_begin(const Wide64Layout& f, const Wide64Buffers& b, hipStream_t s) {
+    return hipMemsetAsync(b.ctl, 0, wide_ctl_words(f) * sizeof(unsigned), s);
+}
+
+template <int TPW>
+static hipError_t wide64_launch(const Wide64Args& a, unsigned grid, hipStream_t s) {
+    hipLaunchKernelGGL((k_fused_wide64<TPW>), dim3(grid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t wide_iterate(const Wide64Layout& f, const Wide64Buffers& b, const UttState& u, int N, int T_, int it_begin,
+                          int it_end, int mode, double eps, double l1, int init_const, int n_cus, hipStream_t s) {
+    if (it_end <= it_begin) return hipSuccess;
+    Wide64Args a = wide64_args(f, b, u, N, T_, mode, eps, l1, init_const);
+    a.it_begin = it_begin; a.it_end = it_end;
+    hipError_t e = hipMemsetAsync(b.ctl, 0, sizeof(unsigned), s);
+    if (e != hipSuccess) return e;
+    const long per_it = (long)f.G * f.c * (f.rmode ? 2 : 1);
+    const long tasks = per_it * (it_end - it_begin);
+    if (n_cus <= 0) n_cus = 256;
+    const unsigned grid = (unsigned)(tasks < n_cus ? tasks : n_cus);
+    switch (f.TPW) {
+        case 5: return wide64_launch<5>(a, grid, s);
+        case 7: return wide64_launch<7>(a, grid, s);
+        case 9: return wide64_launch<9>(a, grid, s);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t wide_err2(const Wide64Layout& f, const Wide64Buffers& b, const UttState& u, int N, int T_, int it, int,
+                     double, double* err2, hipStream_t s) {
+    Wide64Args a = wide64_args(f, b, u, N, T_, 0, 0.0, 0.0, 0);
+    hipLaunchKernelGGL(k_wide64_err2, dim3((unsigned)((f.TT + 3) / 4)), dim3(256), 0, s, a, f.TPW, it, err2);
+    return hipGetLastError();
+}
+
+}  // namespace evc
