@@ -17,7 +17,7 @@ LIB = os.path.join(PKG, "libevc_hip.so")
 SOURCES = ["evc_gemm.hip", "evc_gemm2.hip", "evc_aux.hip", "evc_fused.hip", "evc_fused_res.hip", "evc_fused_all.hip", "evc_wide.hip", "evc_wide64.hip", "evc_gl.hip", "evc_dtw.hip", "evc_api.hip"]
 HEADERS = ["evc_internal.h", "evc_fused_common.h", os.path.join("..", "..", "include", "evc.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
-
+EXTRA_FLAGS = {}
 
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
@@ -49,7 +49,7 @@ def build(force=False, verbose=False):
         s, o, needed = job
         if not needed:
             return 0, ""
-        cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+        cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(os.path.basename(s), []) + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         p = subprocess.run(cmd, capture_output=True, text=True)

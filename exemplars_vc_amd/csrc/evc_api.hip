@@ -96,7 +96,7 @@ template <typename T> DictArrays<T> take_dict(Carver& c, const Dims& d, const Di
         a.B2p = c.take<double>(flB.a2);
     }
     if (p.wide) a.Aw = c.take<float>(wide_layout(d.M, d.N, 1, 256, 0, 0).aw);
-    if (p.wide64) a.Aw64 = c.take<double>(wide64_layout(d.M, d.N, 1, 256, 0).aw);
+    if (p.wide64) a.Aw64 = c.take<double>(wide64_layout(d.M, d.N, 1, 256, 0, 0).aw);
     if (p.bc) a.Bc = c.take<T>((size_t)d.N * d.Mb);
     return a;
 }
@@ -306,7 +306,7 @@ int dict_prepare_typed(const T* A, int lda, const T* B, int ldb, int M, int Mb, 
                                reinterpret_cast<const float*>(a.At), dd.Mk, dd.Np, a.Aw, s));
     }
     if (p.wide64) {
-        const Wide64Layout fl = wide64_layout(M, N, 1, 256, 0);
+        const Wide64Layout fl = wide64_layout(M, N, 1, 256, 0, 0);
         HIP_TRY(wide_pack_dict(fl, reinterpret_cast<const double*>(a.At), nullptr, dd.Mk, dd.Np, a.Aw64, s));
     }
     return ST_OK;
@@ -467,7 +467,9 @@ template <> struct WideKind<double> {
     typedef Wide64Buffers Buffers;
     typedef Wide64Caps Caps;
     static constexpr int kernel = EVC_KERNEL_FUSED_WIDE64;
-    static Layout layout(int M, int N, int T_, int n_cus, int c_req, int) { return wide64_layout(M, N, T_, n_cus, c_req); }
+    static Layout layout(int M, int N, int T_, int n_cus, int c_req, int w_req) {
+        return wide64_layout(M, N, T_, n_cus, c_req, w_req);
+    }
     static Caps caps(int M, int N, int T_, int n_cus) { return wide64_caps(M, N, T_, n_cus); }
     static double* image(const DictArrays<double>& a) { return a.Aw64; }
 };

@@ -262,7 +262,8 @@ struct Wide64Buffers {
 };
 struct Wide64Caps { size_t aw, xw, hw, vpart, vsum, ctl; int c_cap; };
 bool wide64_supported(int M, int N, int T_, int dtype, int algo, int loss);
-Wide64Layout wide64_layout(int M, int N, int T_, int n_cus, int c_req);
+// c_req: 0 = automatic; tpw_req: 0 = the narrowest instance that holds M bins (tests: a wider one)
+Wide64Layout wide64_layout(int M, int N, int T_, int n_cus, int c_req, int tpw_req);
 size_t wide_ctl_words(const Wide64Layout& f);
 Wide64Caps wide64_caps(int M, int N, int T_, int n_cus);
 bool wide_fits(const Wide64Layout& f, const Wide64Caps& k);

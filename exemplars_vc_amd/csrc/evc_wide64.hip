@@ -18,9 +18,13 @@
 //   partial 16 x 16 tiles meet in LDS (16 KiB), and wavefront w reduces and updates ONE QUARTER of the two H tiles
 //   (frame tile w / 2, register pair w % 2: it alone loads that quarter of H and P and stores that quarter of H'),
 //   the four quarters of H' meet in LDS again (4 KiB).  Two LDS-only barriers per block, no global drain.
-// * The dictionary goes global -> registers: the A-operand fragments of a wavefront's own bins are private to it (its
-//   three neighbours hold other bins), so there is nothing to share through LDS; one 16-byte load per lane feeds two
-//   k-steps x two frame tiles = four 64-cycle MFMAs, and a ring of TPW loads (half a product) is in flight.
+// * The dictionary goes global -> LDS -> registers with nothing to share: the A-operand fragments of a wavefront's own
+//   bins are private to it (its three neighbours hold other bins).  A wavefront's fragments are stored in the order
+//   it consumes them (Aw[w][chunk b] = D image of block b, then V' image of block b - 1), so its stream is one linear
+//   walk; it runs through a private ring of 32 KiB-slots filled by LDS-DMA (global_load_lds_dwordx4, no registers,
+//   32 KiB in flight per wavefront - 32 frames per CU means the whole 75 MB image passes every CU once per
+//   iteration, ~16 B/clk/CU at the matrix rate, and latency x bandwidth needs that much in flight); one 16-byte
+//   ds_read per lane feeds two k-steps x two frame tiles = four 64-cycle MFMAs.
 // * The products are software-pipelined across blocks: step i runs D of block i, then V' of block i - 1 - the
 //   partial D tiles travel through LDS, are reduced and turned into H' while V' of the previous block occupies the
 //   matrix pipe.
@@ -34,9 +38,10 @@ typedef unsigned w64_u32x4 __attribute__((ext_vector_type(4)));
 typedef double w64_d2 __attribute__((ext_vector_type(2)));
 
 constexpr long W64_SPIN_LIMIT = 1L << 25;
+constexpr int WIDE64_RING = 32;                    // (a power of two, <= 64: vmcnt is six bits)
 
 struct Wide64Args {
-    const double* Aw;        // [NB][2][4][TPW][2][64][2]   per exemplar block: D-operand image, then V'-operand image
+    const double* Aw;        // [4][NB + 1][2][TPW][2][64][2] per wavefront and chunk b: D image of block b, V' image of block b - 1
     const double* Xw;        // [G][4][2][TPW][2][64][2]    frames in the V chunk layout
     double* Hw;              // [2 G][NB][2][64][2]         activations, quarter-major accumulator order
     double* Pw;              // the same layout: numerators A^T X
@@ -71,17 +76,49 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc64(const void* p, unsigned
 }
 // workgroup barrier that orders LDS traffic only (the global loads in flight stay in flight)
 __device__ __forceinline__ void lds_barrier() {
+#if defined(EVC_W64_ABLATE) && EVC_W64_ABLATE == 3
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return;
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// -DEVC_W64_ABLATE=n (diagnostic builds of tools/ubench/wide64_bench.hip, wrong results): 1: no waits for the fragment
+// loads; 2: no fragment loads at all; 3: no workgroup barriers inside a step; 4: no update arithmetic; 5: no MFMAs
+#ifndef EVC_W64_ABLATE
+#define EVC_W64_ABLATE 0
+#endif
 #ifdef EVC_WIDE_STAMP
-__device__ unsigned long long* evc_wide64_dbg = nullptr;        // [tasks of the launch][8]
-#define W64STAMP(k) do { if (tid == 0 && evc_wide64_dbg) evc_wide64_dbg[(size_t)tk * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define W64NOTE(k, v) do { if (tid == 0 && evc_wide64_dbg) evc_wide64_dbg[(size_t)tk * 8 + (k)] = (unsigned long long)(v); } while (0)
+__device__ unsigned long long* evc_wide64_dbg = nullptr;        // [tasks of the launch][10]
+#define W64STAMP(k) do { if (tid == 0 && evc_wide64_dbg) evc_wide64_dbg[(size_t)tk * 10 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define W64NOTE(k, v) do { if (tid == 0 && evc_wide64_dbg) evc_wide64_dbg[(size_t)tk * 10 + (k)] = (unsigned long long)(v); } while (0)
 #else
 #define W64STAMP(k)
 #define W64NOTE(k, v)
 #endif
+
+// The MFMAs are asm: V (the B operand of D) is pinned to the AGPR half of the register file, every accumulator and the
+// fragments to the VGPR half.  Left to the register allocator (either MFMA form), V' tiles travelled between the two
+// halves around their MFMAs - 150 to 480 copies per block step, each pair of them a dependency stall next to a
+// 64-cycle instruction (V' product at 85 to 103 cycles per MFMA instead of 64).  Wait states the hazard recogniser
+// cannot see: s_nop 1 opens every string (a VALU-written operand or zeroed accumulator -> MFMA: 2 states); an
+// accumulate chain needs none; w64_settle() stands between the last MFMA of an accumulator and any other reader
+// (16-pass DGEMM result -> LDS / memory / VALU read: 18 states).
+__device__ __forceinline__ void w64_mma_a(f64x4& acc, double x, double y_agpr) {
+#if defined(EVC_W64_ABLATE) && EVC_W64_ABLATE == 5
+    acc[0] += x * y_agpr;
+#else
+    asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(x), "a"(y_agpr));
+#endif
+}
+__device__ __forceinline__ void w64_mma_v(f64x4& acc, double x, double y) {
+#if defined(EVC_W64_ABLATE) && EVC_W64_ABLATE == 5
+    acc[0] += x * y;
+#else
+    asm volatile("s_nop 1\n\tv_mfma_f64_16x16x4_f64 %0, %1, %2, %0" : "+v"(acc) : "v"(x), "v"(y));
+#endif
+}
+__device__ __forceinline__ void w64_settle() { asm volatile("s_nop 15\n\ts_nop 3" ::: "memory"); }
 
 template <int TPW>
 __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
@@ -89,11 +126,11 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
     constexpr int KH = (TPW + 1) / 2;                 // bin tiles of the V' product that run before the first barrier
     constexpr unsigned WCH = 2u * TPW * 2048u;        // bytes of a wavefront's V chunk (2 frame tiles x TPW tiles x 2 KiB)
     constexpr unsigned GCH = 4u * WCH;                // ... of a frame group's
-    constexpr unsigned IMGW = NL * 1024u;             // bytes of one (block, product, wavefront) image
-    constexpr int RING = TPW;                         // fragment loads in flight (half a product: 2 TPW x 4 MFMAs)
-    constexpr unsigned OOB = 0xFFFF0000u;             // a buffer offset beyond every resource: the load returns zeros
+    constexpr int R = WIDE64_RING;                    // 1 KiB slots of a wavefront's fragment ring
+    extern __shared__ __attribute__((aligned(16))) char s_ring[];     // [4][R][1024]
     __shared__ w64_d2 s_d[4][2][2][64];               // partial D: [source wavefront][frame tile][register pair][lane]
     __shared__ w64_d2 s_h[2][2][64];                  // H' of the block: [frame tile][register pair][lane]
+    __shared__ w64_d2 s_hp[4][2][64];                 // per wavefront: its quarter of the block's H, then of P
     __shared__ volatile unsigned s_ctl[4];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int q = lane >> 4, i16 = lane & 15;
@@ -103,6 +140,10 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
     const unsigned total = per_it * (unsigned)(a.it_end - a.it_begin);
     const unsigned c = (unsigned)a.c;
     const unsigned lane16 = (unsigned)lane * 16u;
+    char* const ring_w = s_ring + w * (R * 1024);                     // this wavefront's ring
+    const unsigned ring_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring_w + lane16;
+    const unsigned ring_s = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring_w);
+    const unsigned hp_s = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)&s_hp[w][0][0]);
 
     unsigned nxt = 0;
     if (tid == 0) {
@@ -134,8 +175,6 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
         __syncthreads();
         return s_ctl[1] != 0u;
     };
-
-    const __amdgpu_buffer_rsrc_t ra = rsrc64(a.Aw, (unsigned)a.NB * 8u * IMGW);
 
     for (;;) {
         const unsigned tk = __builtin_amdgcn_readfirstlane(s_ctl[0]);
@@ -190,20 +229,38 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
 
         // ---- sweep task (iteration it, frame group g, exemplar range e) ----
         const int j0 = (int)((long)e * a.NB / a.c), j1 = (int)((long)(e + 1) * a.NB / a.c), nb = j1 - j0;
-        // segment s of the fragment stream: s = 2 i is the D image of block j0 + i, s = 2 i + 1 the V' image of block
-        // j0 + i - 1 (none for i = 0); load l of it.  Beyond the range: an out-of-bounds offset (zeros, no traffic).
-        unsigned seg_v = 0, seg_s = 0;                 // offsets of the segment the ring is being refilled from
-        auto seg_set = [&](int s) {
-            const int i = s >> 1, p = s & 1;
-            const bool valid = p ? (i >= 1 && i <= nb) : (i < nb);
-            seg_s = valid ? ((unsigned)(j0 + i - p) * 8u + (unsigned)p * 4u + (unsigned)w) * IMGW : 0u;
-            seg_v = valid ? lane16 : OOB;
+        // The fragment stream of this task: chunks j0 .. j1 of this wavefront's image, 2 NL KiB each (the V' half of the
+        // first and the D half of the last belong to the neighbouring ranges: fetched, not used).  Position p lives in
+        // ring slot p % R; R positions are always in flight (the image is padded by R KiB).
+        const char* gnext = reinterpret_cast<const char*>(a.Aw) +
+                            ((size_t)w * (a.NB + 1) + (size_t)j0) * (2u * NL * 1024u);       // (wave-uniform)
+        unsigned pi = 0, pc = 0;                       // positions issued / consumed
+        // LDS-DMA in asm: a DMA the compiler sees makes it wait for ALL outstanding ones before any LDS read it cannot
+        // prove disjoint, i.e. it would drain the ring at every fragment read.  Hidden from it, the ring's LDS reads are
+        // ordinary loads whose registers and lgkmcnt waits the compiler handles itself (an asm ds_read's destination
+        // would count as written at once: under register pressure hipcc copied such a pending fragment into an AGPR
+        // and reused the register - wrong values, and a fault when the late data landed on an address).  M0 is
+        // saved and restored around it; s_nop 0: M0 written by SALU -> LDS-DMA reads it.
+        auto dma = [&](const char* gbase, unsigned voff, unsigned lds_addr) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff), "s"(lds_addr), "s"(gbase) : "memory");
         };
-        auto seg_load = [&](int l) -> w64_d2 { return ld2(ra, seg_v, seg_s + (unsigned)l * 1024u); };
-        w64_d2 ring[RING];
-        seg_set(0);
+        auto issue = [&]() {
+            if (EVC_W64_ABLATE == 2 || EVC_W64_ABLATE == 7) return;
+            dma(gnext, lane16, ring_s + (pi & (R - 1)) * 1024u);
+            gnext += 1024;
+            ++pi;
+        };
+        // the 16 bytes of this lane in slot p % R (asynchronous: the caller's lgkmcnt wait names the destination)
+        auto fetch = [&](unsigned p) -> w64_d2 {
+            w64_d2 v;
+            if (EVC_W64_ABLATE == 6 || EVC_W64_ABLATE == 7) return w64_d2{1.0 + p, 2.0};
+            asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(ring_a + (p & (R - 1)) * 1024u) : "memory");
+            return v;
+        };
 #pragma unroll
-        for (int l = 0; l < RING; ++l) ring[l] = seg_load(l);      // the dictionary does not depend on anybody
+        for (int l = 0; l < R; ++l) issue();          // the dictionary does not depend on anybody
         if (it > 0 && !wait_for(a.rmode ? a.done_r + g : a.done + g, c * (unsigned)it)) break;
         W64STAMP(1);
 
@@ -256,125 +313,182 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
         const __amdgpu_buffer_rsrc_t rh = rsrc64(a.Hw + (size_t)ft * a.NB * 256, (unsigned)a.NB * 2048u);
         const __amdgpu_buffer_rsrc_t rp = rsrc64(a.Pw + (size_t)ft * a.NB * 256, (unsigned)a.NB * 2048u);
         const unsigned qoff = (unsigned)xq * 1024u + lane16;          // within a 2 KiB tile
+        const char* const hbase = reinterpret_cast<const char*>(a.Hw + (size_t)ft * a.NB * 256);     // (wave-uniform)
+        const char* const pbase = reinterpret_cast<const char*>(a.Pw + (size_t)ft * a.NB * 256);
+        auto dma_sc1 = [&](const char* gbase, unsigned voff, unsigned lds_addr) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 sc1\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff), "s"(lds_addr), "s"(gbase) : "memory");
+        };
         const bool load_h = it > 0 || !a.init_const, load_p = it > 0;
         const int n_edge = (a.N & 15) ? a.NB - 1 : -1;
-        w64_d2 hC = w64_d2{0, 0}, pC = hC, hN = hC, pN = hC;
-        if (nb > 0) {
-            if (load_h) hC = ld2_sc1(rh, qoff, (unsigned)j0 * 2048u);
-            if (load_p) pC = ld2_sc1(rp, qoff, (unsigned)j0 * 2048u);
-        }
         f64x4 hf[2];                                   // H' of the previous block, both frame tiles (B operand of V')
         hf[0] = f64x4{0, 0, 0, 0};
         hf[1] = hf[0];
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R - 1) : "memory");
+        w64_d2 f0 = fetch(0);                          // (the ring was filled before the dependency wait)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f0)::"memory");
         W64STAMP(2);
-        // loads [l0, l1) of the V' product (when `run`: the first step has no previous block); the ring refills with
-        // the rest of this image, then with the first loads of segment s_next
-        auto product_v = [&](auto l0c, auto l1c, bool run, int s_next) {
-            constexpr int l0 = decltype(l0c)::value, l1 = decltype(l1c)::value;
-            if (run) {
+        W64NOTE(8, __builtin_amdgcn_s_memtime());
+        // One section of a product: stream positions pc .. pc + n - 1, four MFMAs each (mf(l, j, fragment), j = 0..3).
+        // A wavefront alone on its SIMD issues in order: whatever stands between two MFMAs runs in the shadow of the
+        // first (64 cycles), whatever follows the last one of a group delays the next group.  So the other work of a
+        // position is dealt out between its MFMAs: after the first the read of position p + 1 from LDS (waited for
+        // after the fourth: it has returned by then), after the second the refill of the slot R positions ahead.
+        // The fragment of position p + 1 is requested from LDS behind the first MFMA of position p and waited for
+        // behind its fourth.  The read is asm with the wait as a second statement naming the registers: the same read
+        // as a C++ load costs 8 cycles per MFMA (tools/ubench/mfma64_fill.hip against mfma64_ports.hip: 72.0 / 66.8
+        // ticks).  Between the two statements the compiler must not touch the destination (it counts as written at
+        // once): tools/asm_audit.py checks the generated code for exactly that.  f0, the fragment of position pc,
+        // is carried from section to section and step to step.
+        // vmcnt counts in order: with R - 2 younger loads issued, vmcnt <= R - 2 says position pc + 1 has landed; other
+        // loads and stores in between only make the wait stricter.
+        auto section = [&](auto nc, auto&& mf, auto&& between) {
+            constexpr int n = decltype(nc)::value;
 #pragma unroll
-                for (int l = l0; l < l1; ++l) {
-                    const int k = l >> 1, h = l & 1;
-                    const w64_d2 fr = ring[l % RING];
-                    Vn[0][k] = Mma<double>::mma(fr[0], hf[0][2 * h], Vn[0][k]);
-                    Vn[1][k] = Mma<double>::mma(fr[0], hf[1][2 * h], Vn[1][k]);
-                    Vn[0][k] = Mma<double>::mma(fr[1], hf[0][2 * h + 1], Vn[0][k]);
-                    Vn[1][k] = Mma<double>::mma(fr[1], hf[1][2 * h + 1], Vn[1][k]);
-                    if (l + RING == NL) seg_set(s_next);
-                    ring[l % RING] = seg_load((l + RING) % NL);
-                }
-            } else if (l1 == NL) {
-                seg_set(s_next);
-#pragma unroll
-                for (int l = 0; l < RING; ++l) ring[l] = seg_load(l);
+            for (int l = 0; l < n; ++l) {
+                mf(l, 0, f0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (EVC_W64_ABLATE != 1 && EVC_W64_ABLATE != 2 && EVC_W64_ABLATE != 7) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R - 2) : "memory");
+                w64_d2 f1 = fetch(pc + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mf(l, 1, f0);
+                __builtin_amdgcn_sched_barrier(0);
+                issue();
+                __builtin_amdgcn_sched_barrier(0);
+                mf(l, 2, f0);
+                __builtin_amdgcn_sched_barrier(0);
+                between(l);
+                __builtin_amdgcn_sched_barrier(0);
+                mf(l, 3, f0);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f1)::"memory");
+                f0 = f1;
+                ++pc;
             }
         };
+        auto nothing = [](int) {};
+        auto mfma_v = [&](int l, int j, const w64_d2& fr) {
+            const int k = l >> 1, h = l & 1, f = j & 1, x = j >> 1;
+            w64_mma_v(Vn[f][k], fr[x], hf[f][2 * h + x]);
+        };
 
+        // step i = 0 .. nb: D of block j0 + i, then V' of block j0 + i - 1.  ONE loop body for every step (peeled first
+        // and last steps made the register allocator shuffle all of V' between two homes in every step): the first
+        // step multiplies the previous range's V' image by H' = 0, the last one forms a D nobody reads (one block's
+        // worth of MFMAs per task).  H and P of the block are requested at the top of the step and used behind the
+        // first barrier, half a step later (nothing loaded is carried from step to step: a loop-carried load would
+        // make the compiler drain the ring).
+#ifdef EVC_W64_TIMERS
+        unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#define W64TICK(k) do { const unsigned long long tn_ = __builtin_amdgcn_s_memtime(); tacc[k] += tn_ - tprev; tprev = tn_; } while (0)
+#else
+#define W64TICK(k)
+#endif
 #pragma clang loop unroll(disable)
         for (int i = 0; i <= nb; ++i) {
+            const bool has_d = i < nb;                 // (wave-uniform)
             const int jb = j0 + i;
-            const bool has_d = i < nb, has_v = i >= 1;
-            if (i + 1 < nb) {
-                if (load_h) hN = ld2_sc1(rh, qoff, (unsigned)(jb + 1) * 2048u);
-                if (load_p) pN = ld2_sc1(rp, qoff, (unsigned)(jb + 1) * 2048u);
+            // H and P quarter of the block -> LDS (sc1: written by another workgroup in the previous iteration); they are the
+            // oldest memory operations of the step, NL + 2 KH fragment loads younger when they are read
+            if (has_d) {
+                if (load_h) dma_sc1(hbase + (size_t)jb * 2048u, qoff, hp_s);
+                if (load_p) dma_sc1(pbase + (size_t)jb * 2048u, qoff, hp_s + 1024u);
             }
-            // ---- D partial of block jb over this wavefront's bins; the ring refills with the V' image of block jb - 1
-            // (refill l of a product's loop: load l + RING of the same segment, then the first RING loads of the next)
+            // ---- D partial of block jb over this wavefront's bins
             f64x4 da[2];
             da[0] = f64x4{0, 0, 0, 0};
             da[1] = da[0];
-            if (has_d) {
+            section(std::integral_constant<int, NL>{}, [&](int l, int j, const w64_d2& fr) {
+                const int k = l >> 1, h = l & 1, f = j & 1, x = j >> 1;
+                w64_mma_a(da[f], fr[x], Vin[f][k][2 * h + x]);
+            }, [&](int l) {
+#ifdef EVC_W64_TIMERS
+                if (l == 3) W64TICK(5);
+                if (l == 11) W64TICK(6);
+#endif
+            });
+            W64TICK(0);
+            w64_settle();
 #pragma unroll
-                for (int l = 0; l < NL; ++l) {
-                    const int k = l >> 1, h = l & 1;
-                    const w64_d2 fr = ring[l % RING];
-                    da[0] = Mma<double>::mma(fr[0], Vin[0][k][2 * h], da[0]);
-                    da[1] = Mma<double>::mma(fr[0], Vin[1][k][2 * h], da[1]);
-                    da[0] = Mma<double>::mma(fr[1], Vin[0][k][2 * h + 1], da[0]);
-                    da[1] = Mma<double>::mma(fr[1], Vin[1][k][2 * h + 1], da[1]);
-                    if (l + RING == NL) seg_set(2 * i + 1);
-                    ring[l % RING] = seg_load((l + RING) % NL);
-                }
-            } else {
-                seg_set(2 * i + 1);
-#pragma unroll
-                for (int l = 0; l < RING; ++l) ring[l] = seg_load(l);
+            for (int f = 0; f < 2; ++f) {
+                const f64x4 d = da[f];
+                s_d[w][f][0][lane] = w64_d2{d[0], d[1]};
+                s_d[w][f][1][lane] = w64_d2{d[2], d[3]};
             }
-            if (has_d) {
-#pragma unroll
-                for (int f = 0; f < 2; ++f) {
-                    const f64x4 d = da[f];
-                    s_d[w][f][0][lane] = w64_d2{d[0], d[1]};
-                    s_d[w][f][1][lane] = w64_d2{d[2], d[3]};
-                }
-            }
-            // ---- V' += A_(jb-1) H'_(jb-1), first half of the bin tiles; the ring refills with the D image of block jb + 1
-            product_v(std::integral_constant<int, 0>{}, std::integral_constant<int, 2 * KH>{}, has_v, 2 * i + 2);
+            // ---- V' += A_(jb-1) H'_(jb-1), first half of the bin tiles
+            section(std::integral_constant<int, 2 * KH>{}, [&](int l, int j, const w64_d2& fr) { mfma_v(l, j, fr); }, nothing);
+            W64TICK(1);
             lds_barrier();                              // the four partial D tiles are in LDS
-            if (has_d) {
-                // reduce this wavefront's quarter in wavefront order, update it
-                w64_d2 dq = s_d[0][ftq][xq][lane];
-                dq += s_d[1][ftq][xq][lane];
-                dq += s_d[2][ftq][xq][lane];
-                dq += s_d[3][ftq][xq][lane];
-                w64_d2 hn;
-                if (it == 0) {
-                    if (a.init_const) {
+            W64TICK(2);
+            // ---- the second half of V' of block jb - 1; between its MFMAs, piece by piece: this wavefront's quarter of D
+            // summed in wavefront order, the update, the quarter of H' to memory and to LDS
+            w64_d2 d0, d1, d2, d3, hn, hC = w64_d2{0, 0}, pC = hC;
+            auto update_piece = [&](int l) {
+                if (!has_d) return;
+                if (l == 0) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL + 2 * KH) : "memory");
+                    if (load_h) hC = s_hp[w][0][lane];
+                    if (load_p) pC = s_hp[w][1][lane];
+                    d0 = s_d[0][ftq][xq][lane];
+                    d1 = s_d[1][ftq][xq][lane];
+                    d2 = s_d[2][ftq][xq][lane];
+                    d3 = s_d[3][ftq][xq][lane];
+                } else if (l == 1) {
+                    d0 = ((d0 + d1) + d2) + d3;
+                    if (it == 0) {
+                        if (a.init_const) {
 #pragma unroll
-                        for (int y = 0; y < 2; ++y) hn[y] = (jb * 16 + q + 4 * (2 * xq + y) < a.N) ? h0v : 0.0;
-                        st2_sc1(rh, qoff, (unsigned)jb * 2048u, hn);
+                            for (int y = 0; y < 2; ++y) hn[y] = (jb * 16 + q + 4 * (2 * xq + y) < a.N) ? h0v : 0.0;
+                        } else {
+                            hn = hC;
+                        }
                     } else {
-                        hn = hC;
+                        hn[0] = EVC_W64_ABLATE == 4 ? hC[0] + 1e-300 * d0[0] : mu_update<double>(hC[0], pC[0], d0[0], a.mode, a.eps, a.l1);
                     }
-                    st2_sc1(rp, qoff, (unsigned)jb * 2048u, dq);
-                } else {
+                } else if (l == 2) {
+                    if (it != 0) {
+                        hn[1] = EVC_W64_ABLATE == 4 ? hC[1] + 1e-300 * d0[1] : mu_update<double>(hC[1], pC[1], d0[1], a.mode, a.eps, a.l1);
+                        if (jb == n_edge) {
 #pragma unroll
-                    for (int y = 0; y < 2; ++y) hn[y] = mu_update<double>(hC[y], pC[y], dq[y], a.mode, a.eps, a.l1);
-                    if (jb == n_edge) {
+                            for (int y = 0; y < 2; ++y) hn[y] = (jb * 16 + q + 4 * (2 * xq + y) < a.N) ? hn[y] : 0.0;
+                        }
 #pragma unroll
-                        for (int y = 0; y < 2; ++y) hn[y] = (jb * 16 + q + 4 * (2 * xq + y) < a.N) ? hn[y] : 0.0;
+                        for (int y = 0; y < 2; ++y) hn[y] = live ? hn[y] : hC[y];
                     }
-#pragma unroll
-                    for (int y = 0; y < 2; ++y) hn[y] = live ? hn[y] : hC[y];
-                    st2_sc1(rh, qoff, (unsigned)jb * 2048u, hn);
+                } else if (l == 3) {
+                    if (it == 0) st2_sc1(rp, qoff, (unsigned)jb * 2048u, d0);
+                    if (it != 0 || a.init_const) st2_sc1(rh, qoff, (unsigned)jb * 2048u, hn);
+                    s_h[ftq][xq][lane] = hn;
                 }
-                s_h[ftq][xq][lane] = hn;
-            }
-            // ---- the second half of V' of block jb - 1
-            product_v(std::integral_constant<int, 2 * KH>{}, std::integral_constant<int, NL>{}, has_v, 2 * i + 2);
+            };
+            static_assert(NL - 2 * KH >= 4, "the update needs four positions of the second half");
+            section(std::integral_constant<int, NL - 2 * KH>{}, [&](int l, int j, const w64_d2& fr) { mfma_v(l + 2 * KH, j, fr); },
+                    update_piece);
+            W64TICK(3);
             lds_barrier();                              // the four quarters of H' are in LDS
-            if (has_d) {
+            W64TICK(4);
 #pragma unroll
-                for (int f = 0; f < 2; ++f) {
-                    const w64_d2 v0 = s_h[f][0][lane], v1 = s_h[f][1][lane];
-                    hf[f] = f64x4{v0[0], v0[1], v1[0], v1[1]};
-                }
+            for (int f = 0; f < 2; ++f) {
+                const w64_d2 v0 = s_h[f][0][lane], v1 = s_h[f][1][lane];
+                hf[f] = f64x4{v0[0], v0[1], v1[0], v1[1]};
             }
-            hC = hN;
-            pC = pN;
         }
 
+#ifdef EVC_W64_TIMERS
+        if (tid == 0 && evc_wide64_dbg) {           // cycles per step: D | V' first half | barrier | V' second half + update | barrier
+            evc_wide64_dbg[(size_t)tk * 10 + 1] = tacc[0] / (nb + 1);
+            evc_wide64_dbg[(size_t)tk * 10 + 4] = tacc[1] / (nb + 1);
+            evc_wide64_dbg[(size_t)tk * 10 + 6] = tacc[2] / (nb + 1);
+            evc_wide64_dbg[(size_t)tk * 10 + 7] = tacc[3] / (nb + 1);
+            evc_wide64_dbg[(size_t)tk * 10 + 8] = tacc[4] / (nb + 1);
+            evc_wide64_dbg[(size_t)tk * 10 + 2] = tacc[5] / (nb + 1);
+            evc_wide64_dbg[(size_t)tk * 10 + 3] = tacc[6] / (nb + 1);
+        }
+#endif
+        w64_settle();
         W64STAMP(3);
+        W64NOTE(9, __builtin_amdgcn_s_memtime());
         // publish the partial V' of this range
         {
             const __amdgpu_buffer_rsrc_t rv =
@@ -403,23 +517,30 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
 // ------------------------------------------------------------------------------------------
 // packing / unpacking
 // ------------------------------------------------------------------------------------------
-// Aw[jb][0][w][k][h][lane = 16 q + i][x] = A[bin 16 (4 k + w) + 4 (2 h + x) + q][exemplar 16 jb + i]       (A operand of D)
-// Aw[jb][1][w][k][h][lane = 16 q + i][x] = A[bin 16 (4 k + w) + i][exemplar 16 jb + 4 (2 h + x) + q]       (A operand of V')
-// At: exemplars as rows (n_rows x ld, zero padded), bins < ld
+// Aw[w][b][0][k][h][lane = 16 q + i][x] = A[bin 16 (4 k + w) + 4 (2 h + x) + q][exemplar 16 b + i]            (A operand of D, block b)
+// Aw[w][b][1][k][h][lane = 16 q + i][x] = A[bin 16 (4 k + w) + i][exemplar 16 (b - 1) + 4 (2 h + x) + q]     (A operand of V', block b - 1)
+// b = 0 .. NB (block -1 and block NB: zeros), then WIDE64_RING KiB of zeros.  At: exemplars as rows (n_rows x ld, zero
+// padded), bins < ld
 __global__ __launch_bounds__(256) void k_wide64_pack_dict(const double* __restrict__ At, int ld, int n_rows, int NB,
-                                                          int TPW, double* __restrict__ Aw) {
+                                                          int TPW, long total, double* __restrict__ Aw) {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    const long per_block = 2L * 4 * TPW * 256;
-    if (gid >= (long)NB * per_block) return;
-    const long jb = gid / per_block;
-    int o = (int)(gid - jb * per_block);
-    const int x = o & 1, lane = (o >> 1) & 63, h = (o >> 7) & 1;
-    o >>= 8;
-    const int k = o % TPW, w = (o / TPW) & 3, p = o / (4 * TPW);
-    const int q = lane >> 4, i = lane & 15, r = 2 * h + x, u = 4 * k + w;
-    const int bin = p ? 16 * u + i : 16 * u + 4 * r + q;
-    const long n = p ? 16 * jb + 4 * r + q : 16 * jb + i;
-    Aw[gid] = (n < n_rows && bin < ld) ? At[n * ld + bin] : 0.0;
+    if (gid >= total) return;
+    const long per_chunk = 2L * TPW * 256, per_wave = (NB + 1) * per_chunk;
+    double v = 0.0;
+    if (gid < 4 * per_wave) {
+        const int w = (int)(gid / per_wave);
+        const long o1 = gid - w * per_wave, b = o1 / per_chunk;
+        int o = (int)(o1 - b * per_chunk);
+        const int x = o & 1, lane = (o >> 1) & 63, h = (o >> 7) & 1;
+        o >>= 8;
+        const int k = o % TPW, p = o / TPW;
+        const int q = lane >> 4, i = lane & 15, r = 2 * h + x, u = 4 * k + w;
+        const long jb = b - p;
+        const int bin = p ? 16 * u + i : 16 * u + 4 * r + q;
+        const long n = p ? 16 * jb + 4 * r + q : 16 * jb + i;
+        if (jb >= 0 && jb < NB && n < n_rows && bin < ld) v = At[n * ld + bin];
+    }
+    Aw[gid] = v;
 }
 
 // Xw[g][w][f][k][h][lane = 16 q + i][x] = X[frame 16 (2 g + f) + i][bin 16 (4 k + w) + q + 4 (2 h + x)]
@@ -517,12 +638,12 @@ bool wide64_supported(int M, int N, int T_, int dtype, int algo, int loss) {
            N >= 16 && T_ >= 1;
 }
 
-Wide64Layout wide64_layout(int M, int N, int T_, int n_cus, int c_req) {
+Wide64Layout wide64_layout(int M, int N, int T_, int n_cus, int c_req, int tpw_req) {
     Wide64Layout f{};
     const int tpw = (M + 63) / 64;
     f.TPW = 9;
     for (int v : WIDE64_TPW_SET)
-        if (v >= tpw) { f.TPW = v; break; }
+        if (v >= tpw && v >= tpw_req) { f.TPW = v; break; }
     f.NB = (N + 15) / 16;
     f.TT = (T_ + 15) / 16;
     f.G = (f.TT + 1) / 2;
@@ -534,7 +655,7 @@ Wide64Layout wide64_layout(int M, int N, int T_, int n_cus, int c_req) {
     f.c = c;
     f.rmode = c > 4 ? 1 : 0;
     const size_t gch = (size_t)4 * 2 * f.TPW * 256;       // doubles per group chunk
-    f.aw = (size_t)f.NB * 2 * 4 * f.TPW * 256;
+    f.aw = (size_t)4 * (f.NB + 1) * 2 * f.TPW * 256 + (size_t)WIDE64_RING * 128;
     f.xw = (size_t)f.G * gch;
     f.hw = (size_t)f.G * 2 * f.NB * 256;
     f.vpart = 2 * (size_t)f.G * f.c * gch;
@@ -543,7 +664,7 @@ Wide64Layout wide64_layout(int M, int N, int T_, int n_cus, int c_req) {
 }
 
 Wide64Caps wide64_caps(int M, int N, int T_, int n_cus) {
-    const Wide64Layout a = wide64_layout(M, N, T_, n_cus, 0);
+    const Wide64Layout a = wide64_layout(M, N, T_, n_cus, 0, 9);      // (room for the widest instance: tests force it)
     Wide64Caps k{};
     int c_cap = a.c;
     if (a.TT <= 4096 && c_cap < 8) c_cap = 8;
@@ -562,14 +683,14 @@ Wide64Caps wide64_caps(int M, int N, int T_, int n_cus) {
 }
 bool wide_fits(const Wide64Layout& f, const Wide64Caps& k) {
     return f.aw <= k.aw && f.xw <= k.xw && f.hw <= k.hw && f.vpart <= k.vpart && f.vsum <= k.vsum &&
-           wide_ctl_words(f) <= k.ctl && f.aw * 8 < 0xFF000000ull;
+           wide_ctl_words(f) <= k.ctl;
 }
 
 hipError_t wide_pack_dict(const Wide64Layout& f, const double* At, const double*, int ld, int n_rows, double* Aw,
                           hipStream_t s) {
     const long n = (long)f.aw;
     hipLaunchKernelGGL(k_wide64_pack_dict, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, At, ld, n_rows, f.NB, f.TPW,
-                       Aw);
+                       n, Aw);
     return hipGetLastError();
 }
 
@@ -613,7 +734,11 @@ hipError_t wide_begin(const Wide64Layout& f, const Wide64Buffers& b, hipStream_t
 
 template <int TPW>
 static hipError_t wide64_launch(const Wide64Args& a, unsigned grid, hipStream_t s) {
-    hipLaunchKernelGGL((k_fused_wide64<TPW>), dim3(grid), dim3(256), 0, s, a);
+    const size_t lds = (size_t)4 * WIDE64_RING * 1024;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_wide64<TPW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_fused_wide64<TPW>), dim3(grid), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 
