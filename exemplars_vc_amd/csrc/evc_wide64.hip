@@ -325,6 +325,8 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
         f64x4 hf[2];                                   // H' of the previous block, both frame tiles (B operand of V')
         hf[0] = f64x4{0, 0, 0, 0};
         hf[1] = hf[0];
+        s_h[ftq][xq][lane] = w64_d2{0, 0};             // (the first step's V' product multiplies by H' = 0)
+        lds_barrier();
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R - 1) : "memory");
         w64_d2 f0 = fetch(0);                          // (the ring was filled before the dependency wait)
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f0)::"memory");
@@ -351,23 +353,26 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (EVC_W64_ABLATE != 1 && EVC_W64_ABLATE != 2 && EVC_W64_ABLATE != 7) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(R - 2) : "memory");
                 w64_d2 f1 = fetch(pc + 1);
+                between(l, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 mf(l, 1, f0);
                 __builtin_amdgcn_sched_barrier(0);
                 issue();
+                between(l, 1);
                 __builtin_amdgcn_sched_barrier(0);
                 mf(l, 2, f0);
                 __builtin_amdgcn_sched_barrier(0);
-                between(l);
+                between(l, 2);
                 __builtin_amdgcn_sched_barrier(0);
                 mf(l, 3, f0);
                 __builtin_amdgcn_sched_barrier(0);
+                between(l, 3);
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f1)::"memory");
                 f0 = f1;
                 ++pc;
             }
         };
-        auto nothing = [](int) {};
+        auto nothing = [](int, int) {};
         auto mfma_v = [&](int l, int j, const w64_d2& fr) {
             const int k = l >> 1, h = l & 1, f = j & 1, x = j >> 1;
             w64_mma_v(Vn[f][k], fr[x], hf[f][2 * h + x]);
@@ -402,11 +407,16 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
             section(std::integral_constant<int, NL>{}, [&](int l, int j, const w64_d2& fr) {
                 const int k = l >> 1, h = l & 1, f = j & 1, x = j >> 1;
                 w64_mma_a(da[f], fr[x], Vin[f][k][2 * h + x]);
-            }, [&](int l) {
-#ifdef EVC_W64_TIMERS
-                if (l == 3) W64TICK(5);
-                if (l == 11) W64TICK(6);
-#endif
+            }, [&](int l, int j) {
+                // H' of the previous block (the B operand of the V' product that follows): read here, three positions
+                // before it is needed - behind the second barrier of the previous step its latency stood in the open
+                if (l == NL - 3 && j == 2) {
+#pragma unroll
+                    for (int f = 0; f < 2; ++f) {
+                        const w64_d2 v0 = s_h[f][0][lane], v1 = s_h[f][1][lane];
+                        hf[f] = f64x4{v0[0], v0[1], v1[0], v1[1]};
+                    }
+                }
             });
             W64TICK(0);
             w64_settle();
@@ -423,10 +433,14 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
             W64TICK(2);
             // ---- the second half of V' of block jb - 1; between its MFMAs, piece by piece: this wavefront's quarter of D
             // summed in wavefront order, the update, the quarter of H' to memory and to LDS
-            w64_d2 d0, d1, d2, d3, hn, hC = w64_d2{0, 0}, pC = hC;
-            auto update_piece = [&](int l) {
+            // (the quotient is the compiler's own correctly rounded f64 division, v_div_scale ... v_div_fixup, written
+            // out so that it can be cut into pieces of a few instructions: one MFMA's 64 cycles cover about that many)
+            w64_d2 d0, d1, d2, d3, hn, hC = w64_d2{0, 0}, pC = hC, num, den, dsc, nsc, rcp, err, quo;
+            bool fl0 = false, fl1 = false;
+            auto update_piece = [&](int l, int j) {
                 if (!has_d) return;
-                if (l == 0) {
+                const int st = 4 * l + j;
+                if (st == 0) {
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL + 2 * KH) : "memory");
                     if (load_h) hC = s_hp[w][0][lane];
                     if (load_p) pC = s_hp[w][1][lane];
@@ -434,8 +448,44 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
                     d1 = s_d[1][ftq][xq][lane];
                     d2 = s_d[2][ftq][xq][lane];
                     d3 = s_d[3][ftq][xq][lane];
-                } else if (l == 1) {
+                } else if (st == 3) {
                     d0 = ((d0 + d1) + d2) + d3;
+                    // numerator and denominator of the surface's update (mu_update, evc_internal.h)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) {
+                        const double dl = d0[y] + a.l1;
+                        switch (a.mode) {
+                            case EVC_EPS_ADD: num[y] = hC[y] * pC[y]; den[y] = dl + a.eps; break;
+                            case EVC_EPS_ZERO_REPLACE: num[y] = pC[y]; den[y] = dl == 0.0 ? a.eps : dl; break;
+                            case EVC_EPS_CLAMP: num[y] = pC[y]; den[y] = dl > a.eps ? dl : a.eps; break;
+                            default: num[y] = hC[y] * pC[y]; den[y] = dl; break;
+                        }
+                    }
+                } else if (st == 4) {
+                    dsc[0] = __builtin_amdgcn_div_scale(num[0], den[0], false, &fl0);
+                    dsc[1] = __builtin_amdgcn_div_scale(num[1], den[1], false, &fl1);
+                } else if (st == 5) {
+                    nsc[0] = __builtin_amdgcn_div_scale(num[0], den[0], true, &fl0);
+                    nsc[1] = __builtin_amdgcn_div_scale(num[1], den[1], true, &fl1);
+                } else if (st == 6) {
+                    rcp[0] = __builtin_amdgcn_rcp(dsc[0]);
+                    rcp[1] = __builtin_amdgcn_rcp(dsc[1]);
+                } else if (st == 7 || st == 8) {
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) {
+                        err[y] = __builtin_fma(-dsc[y], rcp[y], 1.0);
+                        rcp[y] = __builtin_fma(rcp[y], err[y], rcp[y]);
+                    }
+                } else if (st == 9) {
+#pragma unroll
+                    for (int y = 0; y < 2; ++y) {
+                        quo[y] = nsc[y] * rcp[y];
+                        err[y] = __builtin_fma(-dsc[y], quo[y], nsc[y]);
+                    }
+                } else if (st == 10) {
+                    quo[0] = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(err[0], rcp[0], quo[0], fl0), den[0], num[0]);
+                    quo[1] = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(err[1], rcp[1], quo[1], fl1), den[1], num[1]);
+                } else if (st == 11) {
                     if (it == 0) {
                         if (a.init_const) {
 #pragma unroll
@@ -444,19 +494,15 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
                             hn = hC;
                         }
                     } else {
-                        hn[0] = EVC_W64_ABLATE == 4 ? hC[0] + 1e-300 * d0[0] : mu_update<double>(hC[0], pC[0], d0[0], a.mode, a.eps, a.l1);
-                    }
-                } else if (l == 2) {
-                    if (it != 0) {
-                        hn[1] = EVC_W64_ABLATE == 4 ? hC[1] + 1e-300 * d0[1] : mu_update<double>(hC[1], pC[1], d0[1], a.mode, a.eps, a.l1);
-                        if (jb == n_edge) {
 #pragma unroll
-                            for (int y = 0; y < 2; ++y) hn[y] = (jb * 16 + q + 4 * (2 * xq + y) < a.N) ? hn[y] : 0.0;
+                        for (int y = 0; y < 2; ++y) {
+                            hn[y] = (a.mode == EVC_EPS_ZERO_REPLACE || a.mode == EVC_EPS_CLAMP) ? hC[y] * quo[y] : quo[y];
+                            if (EVC_W64_ABLATE == 4) hn[y] = hC[y] + 1e-300 * d0[y];
+                            if (jb == n_edge) hn[y] = (jb * 16 + q + 4 * (2 * xq + y) < a.N) ? hn[y] : 0.0;
+                            hn[y] = live ? hn[y] : hC[y];
                         }
-#pragma unroll
-                        for (int y = 0; y < 2; ++y) hn[y] = live ? hn[y] : hC[y];
                     }
-                } else if (l == 3) {
+                } else if (st == 12) {
                     if (it == 0) st2_sc1(rp, qoff, (unsigned)jb * 2048u, d0);
                     if (it != 0 || a.init_const) st2_sc1(rh, qoff, (unsigned)jb * 2048u, hn);
                     s_h[ftq][xq][lane] = hn;
@@ -468,11 +514,6 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
             W64TICK(3);
             lds_barrier();                              // the four quarters of H' are in LDS
             W64TICK(4);
-#pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                const w64_d2 v0 = s_h[f][0][lane], v1 = s_h[f][1][lane];
-                hf[f] = f64x4{v0[0], v0[1], v1[0], v1[1]};
-            }
         }
 
 #ifdef EVC_W64_TIMERS
@@ -664,7 +705,7 @@ Wide64Layout wide64_layout(int M, int N, int T_, int n_cus, int c_req, int tpw_r
 }
 
 Wide64Caps wide64_caps(int M, int N, int T_, int n_cus) {
-    const Wide64Layout a = wide64_layout(M, N, T_, n_cus, 0, 9);      // (room for the widest instance: tests force it)
+    const Wide64Layout a = wide64_layout(M, N, T_, n_cus, 0, 0);
     Wide64Caps k{};
     int c_cap = a.c;
     if (a.TT <= 4096 && c_cap < 8) c_cap = 8;

@@ -1,0 +1,120 @@
+"""k_fused_wide64 (evc_wide64.hip): the fused FACTORED update for wide float64 spectra (208 < M <= 576 bins; the
+513-bin STFT magnitudes of BASELINE C3 / C5_513).
+
+The kernel is NOT the default route (it ties the two-contraction path at sixteen utterances and loses below:
+DESIGN.md section 5.2b); the tuning bits select it: `fused_w >= 5` (the narrowest instance of 5, 7 or 9 bin tiles per
+wavefront that holds M) and / or `fused_c` (exemplar ranges per frame group).  Every case enters through the C ABI
+and is compared with the float64 oracle on the same inputs; tolerance 1e-9 relative (summation order only: the
+quotient is the correctly rounded division)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+
+
+def oracle():
+    from oracle import evc_oracle as o
+    return o
+
+
+def check(got, want, rtol=RTOL):
+    want = np.asarray(want, dtype=np.float64)
+    np.testing.assert_allclose(np.asarray(got, dtype=np.float64), want, rtol=rtol, atol=1e-12 * float(np.abs(want).max()))
+
+
+def sk_want(o, A, X, K, l1=0.0):
+    N = A.shape[1]
+    return o.mu_solve(A, X, np.full((N, X.shape[1]), np.sqrt(X.mean() / N)), K, eps_mode=o.EPS_ZERO_REPLACE,
+                      eps=float(np.finfo(np.float64).eps), l1=l1, algo="factored")
+
+
+@pytest.mark.parametrize("M,N,T,K,c,tpw", [
+    (513, 256, 64, 12, 0, 9), (513, 256, 64, 12, 1, 9), (513, 256, 40, 12, 2, 9), (513, 250, 50, 12, 3, 9),
+    (513, 1000, 100, 8, 0, 9), (513, 1000, 100, 8, 6, 9), (257, 300, 70, 10, 0, 5), (400, 512, 33, 10, 5, 7),
+    (576, 200, 17, 10, 0, 9), (209, 128, 32, 10, 2, 5), (320, 512, 130, 8, 8, 5), (448, 130, 1, 8, 0, 7),
+    (513, 17, 5, 6, 0, 9),
+])
+def test_wide64_kernel_against_the_oracle(M, N, T, K, c, tpw):
+    import exemplars_vc_amd as evc
+    o = oracle()
+    p = o.synth_problem(M, N, T, seed=M + N + T)
+    got, info = evc.solve_activations(p["A"], p["X"], iters=K, eps_mode="zero_replace", init="sklearn", fused_c=c,
+                                      fused_w=5, info=True)
+    assert info["kernel"] == "k_fused_wide64" and info["launches"] == 1 and info["redo"] == 0, info
+    if c:
+        assert info["members"] == min(c, max(1, ((N + 15) // 16) // 2)), info
+    assert got.dtype == np.float64
+    check(got, sk_want(o, p["A"], p["X"], K))
+
+
+def test_wide64_is_not_the_default_route():
+    """(evc_api.hip, use_wide: off until it beats the two-contraction path)"""
+    import exemplars_vc_amd as evc
+    o = oracle()
+    p = o.synth_problem(513, 256, 64, seed=1)
+    got, info = evc.solve_activations(p["A"], p["X"], iters=5, eps_mode="zero_replace", init="sklearn", info=True)
+    assert info["kernel"] == "k_gemm_nt", info
+    check(got, sk_want(o, p["A"], p["X"], 5))
+
+
+@pytest.mark.parametrize("layout", ["bin_major", "frame_major"])
+@pytest.mark.parametrize("eps_mode,eps", [("add", 1e-9), ("none", 0.0), ("clamp", 1e-15)])
+def test_wide64_other_surfaces_and_convert(layout, eps_mode, eps):
+    """pymf / nmf_tool / deComP semantics with a given H0, the synthesis Y = B H, both orientations"""
+    import exemplars_vc_amd as evc
+    o = oracle()
+    p = o.synth_problem(513, 512, 90, seed=4)
+    A, X, B = p["A"], p["X"], p["B"]
+    H0 = np.random.default_rng(0).random((512, 90)) + 1e-4
+    mode = {"add": o.EPS_ADD, "none": o.EPS_NONE, "clamp": o.EPS_CLAMP}[eps_mode]
+    want = o.mu_solve(A, X, H0, 15, eps_mode=mode, eps=eps, algo="factored")
+    tr = (lambda z: z) if layout == "bin_major" else (lambda z: np.ascontiguousarray(z.T))
+    H, Y = evc.convert(tr(A), tr(X), tr(B), tr(H0), layout=layout, iters=15, eps_mode=eps_mode, eps=eps, fused_w=5)
+    H, Y = (H, Y) if layout == "bin_major" else (H.T, Y.T)
+    check(H, want)
+    check(Y, B @ want)
+
+
+def test_wide64_stop_rule_l1_and_utterances():
+    """scikit-learn's stop rule evaluated between launches on the published V; frozen utterances; l1"""
+    import exemplars_vc_amd as evc
+    o = oracle()
+    p = o.synth_problem(513, 384, 90, seed=9)
+    X_rows, W_rows = np.ascontiguousarray(p["X"].T), np.ascontiguousarray(p["A"].T)
+    offs = np.array([0, 37, 90], dtype=np.int32)
+    H, info = evc.solve_activations(W_rows, X_rows, layout="frame_major", iters=120, eps_mode="zero_replace",
+                                    init="sklearn", check_every=10, stop_rule="sklearn", tol=7e-3, info=True,
+                                    utt_offsets=offs, fused_w=5)
+    assert info["kernel"] == "k_fused_wide64"
+    n_its = []
+    for u in range(2):
+        a, b = offs[u], offs[u + 1]
+        act, n_ref, _ = o.sklearn_mu_fixed_dictionary(X_rows[a:b], W_rows, 120, 7e-3)
+        assert int(info["n_iter"][u]) == n_ref
+        n_its.append(n_ref)
+        check(H[a:b], act, rtol=1e-8)
+    assert min(n_its) < 120, "the tolerance was meant to stop at least one utterance early"
+    got = evc.solve_activations(p["A"], p["X"], iters=10, eps_mode="zero_replace", init="sklearn", l1=0.05, fused_w=5)
+    check(got, sk_want(o, p["A"], p["X"], 10, l1=0.05))
+
+
+def test_wide64_repeatable_and_prepared_dictionary():
+    """bitwise the same from call to call (partials are summed in range order), and from a prepared dictionary"""
+    import exemplars_vc_amd as evc
+    o = oracle()
+    p = o.synth_problem(513, 640, 150, seed=12)
+    kw = dict(iters=8, eps_mode="zero_replace", init="sklearn", fused_c=3, fused_w=5)
+    a = evc.solve_activations(p["A"], p["X"], **kw)
+    b = evc.solve_activations(p["A"], p["X"], **kw)
+    assert np.array_equal(a, b)
+    pd = evc.prepare_dictionary(p["A"], p["B"])
+    c, info = evc.solve_activations(pd, p["X"], info=True, **kw)
+    assert info["kernel"] == "k_fused_wide64" and info["prepared"] == 1, info
+    assert np.array_equal(a, c)
+    # the first 64 frames alone are the first 64 columns of the batch (frame groups are independent)
+    d = evc.solve_activations(p["A"], np.ascontiguousarray(p["X"][:, :64]), iters=8, eps_mode="zero_replace",
+                              init_value=float(np.sqrt(p["X"].mean() / 640)), init="const", fused_c=3, fused_w=5)
+    e = evc.solve_activations(p["A"], p["X"], iters=8, eps_mode="zero_replace",
+                              init_value=float(np.sqrt(p["X"].mean() / 640)), init="const", fused_c=3, fused_w=5)
+    assert np.array_equal(d, e[:, :64])

@@ -9,9 +9,10 @@ typedef unsigned u4 __attribute__((ext_vector_type(4)));
 constexpr int TPW = 9;
 // ACC: 0 = accumulators in VGPRs, 1 = in AGPRs.  FR: 0 = fragment via ds_read into VGPRs, 1 = ds_read into AGPRs,
 // 2 = buffer_load into VGPRs, 3 = no load at all, 4 = two ds_read_b64 into VGPRs
-template <int ACC, int FR>
+template <int ACC, int FR, int BIG = 0>
 __global__ __launch_bounds__(256, 1) void k(double* out, unsigned long long* ticks, int iters, const double* in, const char* stream) {
-    __shared__ __attribute__((aligned(16))) char ring[4][8192];
+    extern __shared__ __attribute__((aligned(16))) char ring_dyn[];
+    char (*ring)[8192] = reinterpret_cast<char (*)[8192]>(ring_dyn + (BIG ? BIG * 1024 : 0));
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     d4 Vin[2][TPW];
     for (int f = 0; f < 2; ++f)
@@ -56,12 +57,12 @@ __global__ __launch_bounds__(256, 1) void k(double* out, unsigned long long* tic
     out[blockIdx.x * blockDim.x + threadIdx.x] = da[0][0] + da[1][1] + fc[0];
     if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
 }
-template <int ACC, int FR> void run(const char* name) {
+template <int ACC, int FR, int BIG = 0> void run(const char* name) {
     double *out, *in; unsigned long long* t; char* stream;
     (void)hipMalloc(&out, 256 * 256 * 8); (void)hipMalloc(&t, 256 * 8); (void)hipMalloc(&in, 4096); (void)hipMalloc(&stream, 65536);
     (void)hipMemset(in, 0, 4096); (void)hipMemset(stream, 0, 65536);
     const int iters = 300;
-    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((k<ACC, FR>), dim3(256), dim3(256), 0, 0, out, t, iters, in, stream);
+    for (int rep = 0; rep < 2; ++rep) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k<ACC, FR, BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64); hipLaunchKernelGGL((k<ACC, FR, BIG>), dim3(256), dim3(256), (BIG + 32) * 1024, 0, out, t, iters, in, stream); }
     (void)hipDeviceSynchronize();
     unsigned long long h[256]; (void)hipMemcpy(h, t, sizeof(h), hipMemcpyDeviceToHost);
     double m = 0; for (int i = 0; i < 256; ++i) m += h[i];
@@ -72,6 +73,9 @@ template <int ACC, int FR> void run(const char* name) {
 int main() {
     run<0, 3>("acc v, no fragment load          ");
     run<0, 0>("acc v, ds_read_b128 -> v         ");
+    run<0, 0, 60>("   ... ring at LDS offset 60 KiB  ");
+    run<0, 0, 100>("   ... ring at LDS offset 100 KiB ");
+    run<0, 0, 120>("   ... ring at LDS offset 120 KiB ");
     run<0, 4>("acc v, 2 x ds_read_b64 -> v      ");
     run<0, 1>("acc v, ds_read_b128 -> a         ");
     run<1, 3>("acc a, no fragment load          ");
