@@ -577,7 +577,10 @@ int solve_wide(const T* A, int lda, const T* X, int ldx, T* H, int ldh, int M, i
     const int init_const = o.init_mode == EVC_INIT_GIVEN ? 0 : 1;
     if (!init_const) HIP_TRY(wide_import_h(fl, w.fb.Hw, H, ldh, fm ? 1 : 0, T_, N, s));
     HIP_TRY(wide_begin(fl, w.fb, s));
-    const int mode = kl ? 100 : o.eps_mode;
+    // (float64: pymf's stop rule compares successive errors against 2.2e-16 and reserved bit 1 asks for it explicitly -
+    // correctly rounded quotients, as in solve_fused)
+    const bool exact = sizeof(T) == 8 && (o.stop_rule == EVC_STOP_PYMF || (o.reserved & 2));
+    const int mode = (kl ? 100 : o.eps_mode) | (exact ? 0x1000 : 0);
 
     inf->kernel = K::kernel;
     inf->members = fl.c;

@@ -60,6 +60,7 @@ struct Wide64Args {
     int mode;                // EVC_EPS_*
     double eps, l1;
     int init_const;
+    int exact;               // 1: correctly rounded quotients (else one shared reciprocal per lane, <= 2 ulp)
 };
 
 __device__ __forceinline__ w64_d2 ld2_sc1(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
@@ -433,14 +434,17 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
             W64TICK(2);
             // ---- the second half of V' of block jb - 1; between its MFMAs, piece by piece: this wavefront's quarter of D
             // summed in wavefront order, the update, the quarter of H' to memory and to LDS
-            // (the quotient is the compiler's own correctly rounded f64 division, v_div_scale ... v_div_fixup, written
-            // out so that it can be cut into pieces of a few instructions: one MFMA's 64 cycles cover about that many)
-            w64_d2 d0, d1, d2, d3, hn, hC = w64_d2{0, 0}, pC = hC, num, den, dsc, nsc, rcp, err, quo;
-            bool fl0 = false, fl1 = false;
+            // f64 VALU work does not hide behind f64 MFMAs (measured: the update costs the same ~1.2 k cycles per step in one
+            // piece, or cut into thirteen pieces dealt out over thirteen gaps - the matrix instruction and the vector
+            // unit's f64 arithmetic do not overlap), so it is kept SHORT rather than spread: three pieces (loads; the
+            // arithmetic; stores), and the two quotients of a lane share one reciprocal, 1 / (den0 den1), refined by two
+            // Newton steps (<= 2 ulp; lanes whose product leaves [1e-280, 1e280], and callers that ask for the
+            // correctly rounded quotient - `exact` - take the division).
+            w64_d2 d0, d1, d2, d3, hn, hC = w64_d2{0, 0}, pC = hC;
             auto update_piece = [&](int l, int j) {
                 if (!has_d) return;
-                const int st = 4 * l + j;
-                if (st == 0) {
+                const int gap = 4 * l + j;
+                if (gap == 2) {
                     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL + 2 * KH) : "memory");
                     if (load_h) hC = s_hp[w][0][lane];
                     if (load_p) pC = s_hp[w][1][lane];
@@ -448,44 +452,8 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
                     d1 = s_d[1][ftq][xq][lane];
                     d2 = s_d[2][ftq][xq][lane];
                     d3 = s_d[3][ftq][xq][lane];
-                } else if (st == 3) {
+                } else if (gap == 6) {
                     d0 = ((d0 + d1) + d2) + d3;
-                    // numerator and denominator of the surface's update (mu_update, evc_internal.h)
-#pragma unroll
-                    for (int y = 0; y < 2; ++y) {
-                        const double dl = d0[y] + a.l1;
-                        switch (a.mode) {
-                            case EVC_EPS_ADD: num[y] = hC[y] * pC[y]; den[y] = dl + a.eps; break;
-                            case EVC_EPS_ZERO_REPLACE: num[y] = pC[y]; den[y] = dl == 0.0 ? a.eps : dl; break;
-                            case EVC_EPS_CLAMP: num[y] = pC[y]; den[y] = dl > a.eps ? dl : a.eps; break;
-                            default: num[y] = hC[y] * pC[y]; den[y] = dl; break;
-                        }
-                    }
-                } else if (st == 4) {
-                    dsc[0] = __builtin_amdgcn_div_scale(num[0], den[0], false, &fl0);
-                    dsc[1] = __builtin_amdgcn_div_scale(num[1], den[1], false, &fl1);
-                } else if (st == 5) {
-                    nsc[0] = __builtin_amdgcn_div_scale(num[0], den[0], true, &fl0);
-                    nsc[1] = __builtin_amdgcn_div_scale(num[1], den[1], true, &fl1);
-                } else if (st == 6) {
-                    rcp[0] = __builtin_amdgcn_rcp(dsc[0]);
-                    rcp[1] = __builtin_amdgcn_rcp(dsc[1]);
-                } else if (st == 7 || st == 8) {
-#pragma unroll
-                    for (int y = 0; y < 2; ++y) {
-                        err[y] = __builtin_fma(-dsc[y], rcp[y], 1.0);
-                        rcp[y] = __builtin_fma(rcp[y], err[y], rcp[y]);
-                    }
-                } else if (st == 9) {
-#pragma unroll
-                    for (int y = 0; y < 2; ++y) {
-                        quo[y] = nsc[y] * rcp[y];
-                        err[y] = __builtin_fma(-dsc[y], quo[y], nsc[y]);
-                    }
-                } else if (st == 10) {
-                    quo[0] = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(err[0], rcp[0], quo[0], fl0), den[0], num[0]);
-                    quo[1] = __builtin_amdgcn_div_fixup(__builtin_amdgcn_div_fmas(err[1], rcp[1], quo[1], fl1), den[1], num[1]);
-                } else if (st == 11) {
                     if (it == 0) {
                         if (a.init_const) {
 #pragma unroll
@@ -493,16 +461,40 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
                         } else {
                             hn = hC;
                         }
+                    } else if (EVC_W64_ABLATE == 4) {
+                        hn = hC + 1e-300 * d0;
                     } else {
+                        // numerator and denominator of the surface's update (mu_update, evc_internal.h)
+                        w64_d2 num, den, quo;
+#pragma unroll
+                        for (int y = 0; y < 2; ++y) {
+                            const double dl = d0[y] + a.l1;
+                            switch (a.mode) {
+                                case EVC_EPS_ADD: num[y] = hC[y] * pC[y]; den[y] = dl + a.eps; break;
+                                case EVC_EPS_ZERO_REPLACE: num[y] = pC[y]; den[y] = dl == 0.0 ? a.eps : dl; break;
+                                case EVC_EPS_CLAMP: num[y] = pC[y]; den[y] = dl > a.eps ? dl : a.eps; break;
+                                default: num[y] = hC[y] * pC[y]; den[y] = dl; break;
+                            }
+                        }
+                        const double m = den[0] * den[1];
+                        if (!a.exact && m > 1e-280 && m < 1e280) {
+                            double r = __builtin_amdgcn_rcp(m);
+                            r = __builtin_fma(__builtin_fma(-m, r, 1.0), r, r);
+                            r = __builtin_fma(__builtin_fma(-m, r, 1.0), r, r);
+                            quo[0] = num[0] * (r * den[1]);
+                            quo[1] = num[1] * (r * den[0]);
+                        } else {
+                            quo[0] = num[0] / den[0];
+                            quo[1] = num[1] / den[1];
+                        }
 #pragma unroll
                         for (int y = 0; y < 2; ++y) {
                             hn[y] = (a.mode == EVC_EPS_ZERO_REPLACE || a.mode == EVC_EPS_CLAMP) ? hC[y] * quo[y] : quo[y];
-                            if (EVC_W64_ABLATE == 4) hn[y] = hC[y] + 1e-300 * d0[y];
                             if (jb == n_edge) hn[y] = (jb * 16 + q + 4 * (2 * xq + y) < a.N) ? hn[y] : 0.0;
                             hn[y] = live ? hn[y] : hC[y];
                         }
                     }
-                } else if (st == 12) {
+                } else if (gap == 10) {
                     if (it == 0) st2_sc1(rp, qoff, (unsigned)jb * 2048u, d0);
                     if (it != 0 || a.init_const) st2_sc1(rh, qoff, (unsigned)jb * 2048u, hn);
                     s_h[ftq][xq][lane] = hn;
@@ -759,13 +751,13 @@ hipError_t wide_export_h(const Wide64Layout& f, const double* Hw, double* H, lon
 }
 
 static Wide64Args wide64_args(const Wide64Layout& f, const Wide64Buffers& b, const UttState& u, int N, int T_, int mode,
-                              double eps, double l1, int init_const) {
+                              double eps, double l1, int init_const, int exact = 0) {
     Wide64Args a{};
     a.Aw = b.Aw; a.Xw = b.Xw; a.Hw = b.Hw; a.Pw = b.Pw; a.Vpart = b.Vpart; a.Vsum = b.Vsum;
     a.ticket = b.ctl; a.done = b.ctl + 4; a.done_r = b.ctl + 4 + f.G; a.abort = reinterpret_cast<int*>(b.ctl + 1);
     a.frame_utt = u.frame_utt; a.active = u.active; a.h0 = u.h0;
     a.NB = f.NB; a.TT = f.TT; a.G = f.G; a.c = f.c; a.rmode = f.rmode;
-    a.N = N; a.T_ = T_; a.mode = mode; a.eps = eps; a.l1 = l1; a.init_const = init_const;
+    a.N = N; a.T_ = T_; a.mode = mode; a.eps = eps; a.l1 = l1; a.init_const = init_const; a.exact = exact;
     return a;
 }
 
@@ -786,7 +778,8 @@ static hipError_t wide64_launch(const Wide64Args& a, unsigned grid, hipStream_t 
 hipError_t wide_iterate(const Wide64Layout& f, const Wide64Buffers& b, const UttState& u, int N, int T_, int it_begin,
                           int it_end, int mode, double eps, double l1, int init_const, int n_cus, hipStream_t s) {
     if (it_end <= it_begin) return hipSuccess;
-    Wide64Args a = wide64_args(f, b, u, N, T_, mode, eps, l1, init_const);
+    // (mode: EVC_EPS_*, + 0x1000 when the caller wants correctly rounded quotients)
+    Wide64Args a = wide64_args(f, b, u, N, T_, mode & 0xfff, eps, l1, init_const, (mode >> 12) & 1);
     a.it_begin = it_begin; a.it_end = it_end;
     hipError_t e = hipMemsetAsync(b.ctl, 0, sizeof(unsigned), s);
     if (e != hipSuccess) return e;
