@@ -403,6 +403,8 @@ def main():
             "k_fused_mu": "k_fused_mu (persistent fused update, activations streamed)",
             "k_fused_wide": "k_fused_wide (fused FACTORED for M > 32: task queue over frame groups x exemplar ranges, "
                             "dictionary blocks shared through LDS, V resident per wavefront, H and P streamed once)",
+            "k_fused_wide64": "k_fused_wide64 (fused FACTORED for float64, 208 < M <= 576: the same task queue; a workgroup's "
+                              "four wavefronts split the bins of 32 frames, fragments through per-wavefront LDS rings)",
             "k_gemm2": "k_gemm2 x2 per iteration (V = H Am^T, then the update as epilogue of V At^T)",
             "k_gemm_nt": "k_gemm_nt x2 per iteration (V = H Am^T, then the update as epilogue of V At^T)",
         }.get(ktag, ktag) + f"; members per frame tile/group: {sinfo.get('members', 1)}"

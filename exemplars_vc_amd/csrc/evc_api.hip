@@ -522,13 +522,19 @@ WideWs<T> carve_wide(void* base, const Dims& d, int n_slots, int n_cus, bool wit
 // dependency hops of the task queue (publish, reduce, gather: measured ~40 us per iteration) outweigh what the
 // fusion saves - 90 against 47 us per iteration for one utterance, 139 / 132 for four, 226 / 241 for eight,
 // 334 / 457 for sixteen (profiles/r03_wide_tuning.md).  The tuning bits (ranges, wavefronts) force the fused
-// kernel at any size.  float64 (k_fused_wide64): a task is long (64-cycle MFMAs), the hops are a few per cent of it.
+// kernel at any size.
 constexpr int WIDE_MIN_TILES = 300;
-constexpr bool WIDE64_DEFAULT = false;      // (until it beats the two-contraction path: forced by the tuning bits)
+// float64 (k_fused_wide64), measured at M = 513, N = 8192 (tools/tune_wide64.py; fraction of the fp64 matrix peak, fused
+// against two contractions): 2 utterances 0.32 / 0.58, 4: 0.62 / 0.59, 6: 0.62 / 0.50, 8: 0.64 / 0.62, 16: 0.64 / 0.62,
+// 32: 0.65 / 0.68, 64: 0.65 / 0.72 - the fused kernel serves the batches in between
+constexpr int WIDE64_MIN_TILES = 160, WIDE64_MAX_TILES = 1000;
 bool use_wide(int M, int N, int T_, int dtype, int algo, int loss, int reserved) {
     if (reserved & EVC_FLAG_NO_FUSED) return false;
     const bool forced = ((reserved >> 8) & 0xff) != 0 || ((reserved >> 16) & 0xf) != 0;
-    if (dtype == EVC_F64) return wide64_supported(M, N, T_, dtype, algo, loss) && (forced || WIDE64_DEFAULT);
+    if (dtype == EVC_F64) {
+        const int tiles = (T_ + 15) / 16;
+        return wide64_supported(M, N, T_, dtype, algo, loss) && (forced || (tiles >= WIDE64_MIN_TILES && tiles <= WIDE64_MAX_TILES));
+    }
     if (!wide_supported(M, N, T_, dtype, algo)) return false;
     return forced || (T_ + 15) / 16 >= WIDE_MIN_TILES;
 }

@@ -1,9 +1,9 @@
 """k_fused_wide64 (evc_wide64.hip): the fused FACTORED update for wide float64 spectra (208 < M <= 576 bins; the
 513-bin STFT magnitudes of BASELINE C3 / C5_513).
 
-The kernel is NOT the default route (it ties the two-contraction path at sixteen utterances and loses below:
-DESIGN.md section 5.2b); the tuning bits select it: `fused_w >= 5` (the narrowest instance of 5, 7 or 9 bin tiles per
-wavefront that holds M) and / or `fused_c` (exemplar ranges per frame group).  Every case enters through the C ABI
+The library routes batches of 160 ... 1000 frame tiles to it (4 to ~20 utterances: DESIGN.md section 5.2b, where it
+beats the two-contraction path); elsewhere the tuning bits select it: `fused_w >= 5` (the narrowest instance of 5, 7
+or 9 bin tiles per wavefront that holds M) and / or `fused_c` (exemplar ranges per frame group).  Every case enters through the C ABI
 and is compared with the float64 oracle on the same inputs; tolerance 1e-9 relative (summation order only: the
 quotient is the correctly rounded division)."""
 import numpy as np
@@ -48,14 +48,15 @@ def test_wide64_kernel_against_the_oracle(M, N, T, K, c, tpw):
     check(got, sk_want(o, p["A"], p["X"], K))
 
 
-def test_wide64_is_not_the_default_route():
-    """(evc_api.hip, use_wide: off until it beats the two-contraction path)"""
+def test_wide64_routing_by_batch_size():
+    """(evc_api.hip, use_wide: the fused kernel serves 160 ... 1000 frame tiles, where it beats the two contractions)"""
     import exemplars_vc_amd as evc
     o = oracle()
-    p = o.synth_problem(513, 256, 64, seed=1)
-    got, info = evc.solve_activations(p["A"], p["X"], iters=5, eps_mode="zero_replace", init="sklearn", info=True)
-    assert info["kernel"] == "k_gemm_nt", info
-    check(got, sk_want(o, p["A"], p["X"], 5))
+    for T, kernel in ((64, "k_gemm_nt"), (2700, "k_fused_wide64")):
+        p = o.synth_problem(513, 256, T, seed=T)
+        got, info = evc.solve_activations(p["A"], p["X"], iters=4, eps_mode="zero_replace", init="sklearn", info=True)
+        assert info["kernel"] == kernel, info
+        check(got, sk_want(o, p["A"], p["X"], 4))
 
 
 @pytest.mark.parametrize("layout", ["bin_major", "frame_major"])
