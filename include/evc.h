@@ -105,7 +105,8 @@ enum { EVC_LOSS_FROBENIUS = 0, EVC_LOSS_KL = 1 };
 
 /* evc_solve_opts.reserved
  *   NO_FUSED         the generic two-contraction path instead of the fused persistent kernels (M <= 32)
- *   EXACT_DIV        correctly rounded quotients in the fused kernels (always on with EVC_STOP_PYMF)
+ *   EXACT_DIV        correctly rounded quotients in the fused float64 kernels (always on with EVC_STOP_PYMF;
+ *                    else a shared / refined reciprocal, <= 2 ulp)
  *   NO_EXCHANGE      no kernel in which workgroups exchange data inside a launch: the call is then fully
  *                    asynchronous (see "Host synchronisation" above); a latency / determinism knob
  *   NO_ALL_RESIDENT  keep k_fused_all out (k_fused_res, with its cooperative launch for few frame tiles) */
@@ -123,8 +124,11 @@ typedef struct evc_solve_opts {
     int init_mode;     /* EVC_INIT_* */
     int check_every;   /* 0: never evaluate the residual; k>0: every k iterations */
     int stop_rule;     /* EVC_STOP_* */
-    int reserved;      /* flags, 0 = defaults: an OR of EVC_FLAG_* (below); bits 8..15: tuning only - 1 | 2 force the
-                          general streamed kernel with that many frame tiles per workgroup */
+    int reserved;      /* flags, 0 = defaults: an OR of EVC_FLAG_* (below); bits 8..15: tuning only - M <= 32: 1 | 2 force
+                          the general streamed kernel with that many frame tiles per workgroup; M > 32: that many exemplar
+                          ranges per frame group in k_fused_wide / k_fused_wide64, whatever the batch size; bits 16..19,
+                          tuning only: k_fused_wide with 4 | 8 wavefronts per workgroup, k_fused_wide64 with >= 5 | 7 | 9
+                          bin tiles per wavefront */
     int loss;          /* EVC_LOSS_* */
     int test_abort_at; /* 0 in production.  Tests only: k > 0 pretends, in front of the k-th launch of the iteration
                           loop, that a workgroup gave up waiting for its peers (the abort flag is raised as a timed-out
