@@ -55,7 +55,7 @@ struct DictPlan {
     bool fused;          // float64 fused kernels (M <= 32): operand fragments, row sums
     bool packed_b;       // ... and B's fragments for the synthesis from packed tiles (1 <= Mb <= 32)
     bool wide;           // k_fused_wide's block images (float32, 32 < M <= 208)
-    bool wide64;         // k_fused_wide64's block images (float64, 208 < M <= 576, Frobenius)
+    bool wide64;         // k_fused_wide64's block images (float64, 208 < M <= 528, Frobenius)
     bool kl;             // the dictionary divided by its column sums
     bool bc;             // a compact exemplars-as-rows copy of B (prepared images: the caller's B is not consulted)
 };

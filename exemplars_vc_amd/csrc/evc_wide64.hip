@@ -1,4 +1,4 @@
-// k_fused_wide64: the fused FACTORED multiplicative update for wide float64 spectra (208 < M <= 576 bins: the
+// k_fused_wide64: the fused FACTORED multiplicative update for wide float64 spectra (208 < M <= 528 bins: the
 // 513-bin STFT magnitudes of BASELINE C3 / C5_513; 04_align_n_nmf.py:315-326 with fft_size 1024).
 //
 //   per iteration and frame:  D = A^T V (+ l1, + eps)      V = A H of the previous iteration
@@ -14,6 +14,11 @@
 //   accumulator tiles each).  For the 16x16x4 f64 MFMA the accumulator layout (lane = (q, frame), register r <->
 //   row q + 4 r) is the B-operand layout of k-step r (rows 4 r + q): V' feeds the next D product and D / H' feed
 //   V' += A_j H'_j without a shuffle, as in the float32 kernel.
+// * One bin tile more than the wavefronts hold whole (bins 64 TPW ... 64 TPW + 15: the 513th bin of a 1024-point
+//   spectrum would cost every wavefront a ninth tile) is split over them by k-step: wavefront w multiplies rows
+//   4 w .. 4 w + 3 of it into its partial D, and k-step w (exemplars 4 w .. 4 w + 3) of the block into a partial
+//   sum of that tile's V'; the four partial sums are added up by whoever reads V next.  One fragment position and
+//   four MFMAs per block instead of sixteen.
 // * D = A_j^T V needs all bins: every wavefront multiplies its own bins (2 TPW k-steps of 4 per frame tile), the four
 //   partial 16 x 16 tiles meet in LDS (16 KiB), and wavefront w reduces and updates ONE QUARTER of the two H tiles
 //   (frame tile w / 2, register pair w % 2: it alone loads that quarter of H and P and stores that quarter of H'),
@@ -41,12 +46,13 @@ constexpr long W64_SPIN_LIMIT = 1L << 25;
 constexpr int WIDE64_RING = 32;                    // (a power of two, <= 64: vmcnt is six bits)
 
 struct Wide64Args {
-    const double* Aw;        // [4][NB + 1][2][TPW][2][64][2] per wavefront and chunk b: D image of block b, V' image of block b - 1
-    const double* Xw;        // [G][4][2][TPW][2][64][2]    frames in the V chunk layout
+    const double* Aw;        // [4][NB + 1][2 NL + 1][64][2] per wavefront and chunk b: D image of block b (NL = 2 TPW positions), the
+                             // extra tile's position (D fragment of block b, V' fragment of block b - 1), V' image of block b - 1
+    const double* Xw;        // [G][4][2][TPW + 1][2][64][2]    frames in the V chunk layout (slot TPW: the extra tile, partial per wavefront)
     double* Hw;              // [2 G][NB][2][64][2]         activations, quarter-major accumulator order
     double* Pw;              // the same layout: numerators A^T X
-    double* Vpart;           // [2][G][c][4][2][TPW][2][64][2]
-    double* Vsum;            // [2][G][4][2][TPW][2][64][2]   (reduce mode)
+    double* Vpart;           // [2][G][c][4][2][TPW + 1][2][64][2]
+    double* Vsum;            // [2][G][4][2][TPW + 1][2][64][2]   (reduce mode)
     unsigned* ticket;
     unsigned* done;          // [G]
     unsigned* done_r;        // [G]
@@ -125,7 +131,9 @@ template <int TPW>
 __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
     constexpr int NL = 2 * TPW;                       // 16-byte fragment loads per product and wavefront
     constexpr int KH = (TPW + 1) / 2;                 // bin tiles of the V' product that run before the first barrier
-    constexpr unsigned WCH = 2u * TPW * 2048u;        // bytes of a wavefront's V chunk (2 frame tiles x TPW tiles x 2 KiB)
+    constexpr int TS = TPW + 1;                       // tile slots per frame tile in a wavefront's V chunk (the last: the extra tile)
+    constexpr int CP = 2 * NL + 1;                    // fragment positions per block (chunk)
+    constexpr unsigned WCH = 2u * TS * 2048u;         // bytes of a wavefront's V chunk (2 frame tiles x TS slots x 2 KiB)
     constexpr unsigned GCH = 4u * WCH;                // ... of a frame group's
     constexpr int R = WIDE64_RING;                    // 1 KiB slots of a wavefront's fragment ring
     extern __shared__ __attribute__((aligned(16))) char s_ring[];     // [4][R][1024]
@@ -230,11 +238,11 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
 
         // ---- sweep task (iteration it, frame group g, exemplar range e) ----
         const int j0 = (int)((long)e * a.NB / a.c), j1 = (int)((long)(e + 1) * a.NB / a.c), nb = j1 - j0;
-        // The fragment stream of this task: chunks j0 .. j1 of this wavefront's image, 2 NL KiB each (the V' half of the
+        // The fragment stream of this task: chunks j0 .. j1 of this wavefront's image, 2 NL + 1 KiB each (the V' half of the
         // first and the D half of the last belong to the neighbouring ranges: fetched, not used).  Position p lives in
         // ring slot p % R; R positions are always in flight (the image is padded by R KiB).
         const char* gnext = reinterpret_cast<const char*>(a.Aw) +
-                            ((size_t)w * (a.NB + 1) + (size_t)j0) * (2u * NL * 1024u);       // (wave-uniform)
+                            ((size_t)w * (a.NB + 1) + (size_t)j0) * (CP * 1024u);             // (wave-uniform)
         unsigned pi = 0, pc = 0;                       // positions issued / consumed
         // LDS-DMA in asm: a DMA the compiler sees makes it wait for ALL outstanding ones before any LDS read it cannot
         // prove disjoint, i.e. it would drain the ring at every fragment read.  Hidden from it, the ring's LDS reads are
@@ -266,7 +274,8 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
         W64STAMP(1);
 
         // V of this wavefront's bins, both frame tiles
-        f64x4 Vin[2][TPW], Vn[2][TPW];
+        f64x4 Vin[2][TPW], Vn[2][TPW], Vo[2];
+        double Vodd[2] = {0.0, 0.0};                   // rows 4 w + q of the extra tile of V (B operand of its k-step w)
         {
             const double* src;
             unsigned nsum = 1, stride = 0;
@@ -283,19 +292,29 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
             const unsigned wbase = (unsigned)w * WCH;
             for (unsigned m = 0; m < nsum; ++m) {
 #pragma unroll
-                for (int f = 0; f < 2; ++f)
+                for (int f = 0; f < 2; ++f) {
 #pragma unroll
                     for (int k = 0; k < TPW; ++k) {
-                        const unsigned o = wbase + (unsigned)((f * TPW + k) * 2) * 1024u + lane16;
+                        const unsigned o = wbase + (unsigned)((f * TS + k) * 2) * 1024u + lane16;
                         const w64_d2 v0 = ld2_sc1(rv, o, m * stride), v1 = ld2_sc1(rv, o + 1024u, m * stride);
                         const f64x4 v = f64x4{v0[0], v0[1], v1[0], v1[1]};
                         Vin[f][k] = m ? Vin[f][k] + v : v;
                     }
+                    // the extra tile: register w of the sum of the four wavefronts' partial tiles (range order, then
+                    // wavefront order)
+#pragma unroll
+                    for (unsigned ws = 0; ws < 4; ++ws) {
+                        const w64_d2 v = ld2_sc1(rv, ws * WCH + (unsigned)((f * TS + TPW) * 2 + (w >> 1)) * 1024u + lane16, m * stride);
+                        Vodd[f] += (w & 1) ? v[1] : v[0];
+                    }
+                }
             }
 #pragma unroll
-            for (int f = 0; f < 2; ++f)
+            for (int f = 0; f < 2; ++f) {
 #pragma unroll
                 for (int k = 0; k < TPW; ++k) Vn[f][k] = f64x4{0, 0, 0, 0};
+                Vo[f] = f64x4{0, 0, 0, 0};
+            }
         }
         // the quarter of H / P this wavefront owns: frame tile 2 g + ftq, registers 2 xq, 2 xq + 1
         const int ft = 2 * g + ftq;
@@ -324,6 +343,7 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
         const bool load_h = it > 0 || !a.init_const, load_p = it > 0;
         const int n_edge = (a.N & 15) ? a.NB - 1 : -1;
         f64x4 hf[2];                                   // H' of the previous block, both frame tiles (B operand of V')
+        double hfw[2] = {0.0, 0.0};                    // ... and its register w (B operand of the extra tile's k-step w)
         hf[0] = f64x4{0, 0, 0, 0};
         hf[1] = hf[0];
         s_h[ftq][xq][lane] = w64_d2{0, 0};             // (the first step's V' product multiplies by H' = 0)
@@ -367,8 +387,9 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
                 __builtin_amdgcn_sched_barrier(0);
                 mf(l, 3, f0);
                 __builtin_amdgcn_sched_barrier(0);
-                between(l, 3);
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f1)::"memory");
+                between(l, 3);               // (branchy work belongs here: outside the window in which f1 is pending)
+                __builtin_amdgcn_sched_barrier(0);
                 f0 = f1;
                 ++pc;
             }
@@ -396,7 +417,7 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
             const bool has_d = i < nb;                 // (wave-uniform)
             const int jb = j0 + i;
             // H and P quarter of the block -> LDS (sc1: written by another workgroup in the previous iteration); they are the
-            // oldest memory operations of the step, NL + 2 KH fragment loads younger when they are read
+            // oldest memory operations of the step, NL + 1 + 2 KH fragment loads younger when they are read
             if (has_d) {
                 if (load_h) dma_sc1(hbase + (size_t)jb * 2048u, qoff, hp_s);
                 if (load_p) dma_sc1(pbase + (size_t)jb * 2048u, qoff, hp_s + 1024u);
@@ -416,9 +437,15 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
                     for (int f = 0; f < 2; ++f) {
                         const w64_d2 v0 = s_h[f][0][lane], v1 = s_h[f][1][lane];
                         hf[f] = f64x4{v0[0], v0[1], v1[0], v1[1]};
+                        hfw[f] = reinterpret_cast<const double*>(&s_h[f][w >> 1][lane])[w & 1];     // (register w of it)
                     }
                 }
             });
+            // ---- the extra tile's position: rows 4 w + q of it into the partial D; k-step w of block jb - 1 into its V'
+            section(std::integral_constant<int, 1>{}, [&](int, int j, const w64_d2& fr) {
+                if (j < 2) w64_mma_v(da[j], fr[0], Vodd[j]);
+                else w64_mma_v(Vo[j - 2], fr[1], hfw[j - 2]);
+            }, nothing);
             W64TICK(0);
             w64_settle();
 #pragma unroll
@@ -444,15 +471,15 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
             auto update_piece = [&](int l, int j) {
                 if (!has_d) return;
                 const int gap = 4 * l + j;
-                if (gap == 2) {
-                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL + 2 * KH) : "memory");
+                if (gap == 3) {
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NL + 1 + 2 * KH) : "memory");
                     if (load_h) hC = s_hp[w][0][lane];
                     if (load_p) pC = s_hp[w][1][lane];
                     d0 = s_d[0][ftq][xq][lane];
                     d1 = s_d[1][ftq][xq][lane];
                     d2 = s_d[2][ftq][xq][lane];
                     d3 = s_d[3][ftq][xq][lane];
-                } else if (gap == 6) {
+                } else if (gap == 7) {
                     d0 = ((d0 + d1) + d2) + d3;
                     if (it == 0) {
                         if (a.init_const) {
@@ -494,13 +521,13 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
                             hn[y] = live ? hn[y] : hC[y];
                         }
                     }
-                } else if (gap == 10) {
+                } else if (gap == 11) {
                     if (it == 0) st2_sc1(rp, qoff, (unsigned)jb * 2048u, d0);
                     if (it != 0 || a.init_const) st2_sc1(rh, qoff, (unsigned)jb * 2048u, hn);
                     s_h[ftq][xq][lane] = hn;
                 }
             };
-            static_assert(NL - 2 * KH >= 4, "the update needs four positions of the second half");
+            static_assert(NL - 2 * KH >= 3, "the update needs three positions of the second half");
             section(std::integral_constant<int, NL - 2 * KH>{}, [&](int l, int j, const w64_d2& fr) { mfma_v(l + 2 * KH, j, fr); },
                     update_piece);
             W64TICK(3);
@@ -529,10 +556,11 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
 #pragma unroll
             for (int f = 0; f < 2; ++f)
 #pragma unroll
-                for (int k = 0; k < TPW; ++k) {
-                    const unsigned o = (unsigned)((f * TPW + k) * 2) * 1024u + lane16;
-                    st2_sc1(rv, o, 0, w64_d2{Vn[f][k][0], Vn[f][k][1]});
-                    st2_sc1(rv, o + 1024u, 0, w64_d2{Vn[f][k][2], Vn[f][k][3]});
+                for (int k = 0; k < TS; ++k) {
+                    const f64x4 v = k < TPW ? Vn[f][k < TPW ? k : 0] : Vo[f];
+                    const unsigned o = (unsigned)((f * TS + k) * 2) * 1024u + lane16;
+                    st2_sc1(rv, o, 0, w64_d2{v[0], v[1]});
+                    st2_sc1(rv, o + 1024u, 0, w64_d2{v[2], v[3]});
                 }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -550,47 +578,63 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
 // ------------------------------------------------------------------------------------------
 // packing / unpacking
 // ------------------------------------------------------------------------------------------
-// Aw[w][b][0][k][h][lane = 16 q + i][x] = A[bin 16 (4 k + w) + 4 (2 h + x) + q][exemplar 16 b + i]            (A operand of D, block b)
-// Aw[w][b][1][k][h][lane = 16 q + i][x] = A[bin 16 (4 k + w) + i][exemplar 16 (b - 1) + 4 (2 h + x) + q]     (A operand of V', block b - 1)
+// Aw[w][b][position][lane = 16 q + i][x], position = 0 .. 2 NL (NL = 2 TPW):
+//   position 2 k + h           : A[bin 16 (4 k + w) + 4 (2 h + x) + q][exemplar 16 b + i]              (A operand of D, block b)
+//   position NL                : x = 0: A[bin 64 TPW + 4 w + q][exemplar 16 b + i]                     (the extra tile: D, rows 4 w + q)
+//                                x = 1: A[bin 64 TPW + i][exemplar 16 (b - 1) + 4 w + q]               (... V' of block b - 1, k-step w)
+//   position NL + 1 + 2 k + h  : A[bin 16 (4 k + w) + i][exemplar 16 (b - 1) + 4 (2 h + x) + q]        (A operand of V', block b - 1)
 // b = 0 .. NB (block -1 and block NB: zeros), then WIDE64_RING KiB of zeros.  At: exemplars as rows (n_rows x ld, zero
 // padded), bins < ld
 __global__ __launch_bounds__(256) void k_wide64_pack_dict(const double* __restrict__ At, int ld, int n_rows, int NB,
                                                           int TPW, long total, double* __restrict__ Aw) {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
     if (gid >= total) return;
-    const long per_chunk = 2L * TPW * 256, per_wave = (NB + 1) * per_chunk;
+    const int NL = 2 * TPW;
+    const long per_chunk = (2L * NL + 1) * 128, per_wave = (NB + 1) * per_chunk;
     double v = 0.0;
     if (gid < 4 * per_wave) {
         const int w = (int)(gid / per_wave);
         const long o1 = gid - w * per_wave, b = o1 / per_chunk;
-        int o = (int)(o1 - b * per_chunk);
-        const int x = o & 1, lane = (o >> 1) & 63, h = (o >> 7) & 1;
-        o >>= 8;
-        const int k = o % TPW, p = o / TPW;
-        const int q = lane >> 4, i = lane & 15, r = 2 * h + x, u = 4 * k + w;
-        const long jb = b - p;
-        const int bin = p ? 16 * u + i : 16 * u + 4 * r + q;
-        const long n = p ? 16 * jb + 4 * r + q : 16 * jb + i;
-        if (jb >= 0 && jb < NB && n < n_rows && bin < ld) v = At[n * ld + bin];
+        const int o = (int)(o1 - b * per_chunk);
+        const int x = o & 1, lane = (o >> 1) & 63, pos = o >> 7;
+        const int q = lane >> 4, i = lane & 15;
+        int bin;
+        long n;
+        if (pos < NL) {
+            const int k = pos >> 1, h = pos & 1;
+            bin = 16 * (4 * k + w) + 4 * (2 * h + x) + q;
+            n = 16 * b + i;
+        } else if (pos == NL) {
+            bin = x ? 64 * TPW + i : 64 * TPW + 4 * w + q;
+            n = x ? 16 * (b - 1) + 4 * w + q : 16 * b + i;
+        } else {
+            const int k = (pos - NL - 1) >> 1, h = (pos - NL - 1) & 1;
+            bin = 16 * (4 * k + w) + i;
+            n = 16 * (b - 1) + 4 * (2 * h + x) + q;
+        }
+        const long jb = n >> 4;          // (n >= -16: block -1 is n < 0)
+        if (n >= 0 && jb < NB && n < n_rows && bin < ld) v = At[n * ld + bin];
     }
     Aw[gid] = v;
 }
 
-// Xw[g][w][f][k][h][lane = 16 q + i][x] = X[frame 16 (2 g + f) + i][bin 16 (4 k + w) + q + 4 (2 h + x)]
+// Xw[g][w][f][k][h][lane = 16 q + i][x] = X[frame 16 (2 g + f) + i][bin 16 (4 k + w) + q + 4 (2 h + x)], k < TPW;
+// slot k = TPW: the extra tile, X[frame][bin 64 TPW + q + 4 (2 h + x)] in wavefront 0's slot, zeros in the others
 __global__ __launch_bounds__(256) void k_wide64_pack_x(const double* __restrict__ Xt, int ld, int rows, long G, int TPW,
                                                        double* __restrict__ Xw) {
     const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    const long per_group = 4L * 2 * TPW * 256;
+    const int TS = TPW + 1;
+    const long per_group = 4L * 2 * TS * 256;
     if (gid >= G * per_group) return;
     const long g = gid / per_group;
     int o = (int)(gid - g * per_group);
     const int x = o & 1, lane = (o >> 1) & 63, h = (o >> 7) & 1;
     o >>= 8;
-    const int k = o % TPW, f = (o / TPW) & 1, w = o / (2 * TPW);
+    const int k = o % TS, f = (o / TS) & 1, w = o / (2 * TS);
     const int q = lane >> 4, i = lane & 15;
     const long t = 16 * (2 * g + f) + i;
-    const int bin = 16 * (4 * k + w) + q + 4 * (2 * h + x);
-    Xw[gid] = (t < rows && bin < ld) ? Xt[t * ld + bin] : 0.0;
+    const int bin = k < TPW ? 16 * (4 * k + w) + q + 4 * (2 * h + x) : 64 * TPW + q + 4 * (2 * h + x);
+    Xw[gid] = (t < rows && bin < ld && (k < TPW || w == 0)) ? Xt[t * ld + bin] : 0.0;
 }
 
 // Hw[ft][jb][x][lane = 16 q + i][y] <-> H[exemplar 16 jb + q + 4 (2 x + y)][frame 16 ft + i]
@@ -635,24 +679,33 @@ __global__ __launch_bounds__(256) void k_wide64_err2(Wide64Args a, int TPW, int 
     if (ft >= a.TT) return;
     const int g = (int)(ft >> 1), f = (int)(ft & 1);
     const unsigned par = (unsigned)(it & 1);
-    const size_t wch = (size_t)2 * TPW * 128, gch = 4 * wch;          // 16-byte units
+    const int TS = TPW + 1;
+    const size_t wch = (size_t)2 * TS * 128, gch = 4 * wch;           // 16-byte units
     const w64_d2* xw = reinterpret_cast<const w64_d2*>(a.Xw) + (size_t)g * gch;
     const w64_d2* vs = reinterpret_cast<const w64_d2*>(a.Vsum) + (size_t)(par * a.G + g) * gch;
     const w64_d2* vp = reinterpret_cast<const w64_d2*>(a.Vpart) + (size_t)(par * a.G + g) * a.c * gch;
+    auto v_at = [&](size_t o) {
+        if (a.rmode) return vs[o];
+        w64_d2 v = vp[o];
+        for (int m = 1; m < a.c; ++m) v += vp[(size_t)m * gch + o];
+        return v;
+    };
     double acc = 0.0;
     for (int w = 0; w < 4; ++w)
         for (int kh = 0; kh < 2 * TPW; ++kh) {
-            const size_t o = (size_t)w * wch + ((size_t)f * 2 * TPW + kh) * 64 + lane;
-            w64_d2 v;
-            if (a.rmode) {
-                v = vs[o];
-            } else {
-                v = vp[o];
-                for (int m = 1; m < a.c; ++m) v += vp[(size_t)m * gch + o];
-            }
-            const w64_d2 x = xw[o];
+            const size_t o = (size_t)w * wch + ((size_t)f * 2 * TS + kh) * 64 + lane;
+            const w64_d2 v = v_at(o), x = xw[o];
             acc += (x[0] - v[0]) * (x[0] - v[0]) + (x[1] - v[1]) * (x[1] - v[1]);
         }
+    for (int h = 0; h < 2; ++h) {            // the extra tile: the four wavefronts' partial sums first
+        w64_d2 v = w64_d2{0, 0}, x = v;
+        for (int w = 0; w < 4; ++w) {
+            const size_t o = (size_t)w * wch + ((size_t)f * 2 * TS + 2 * TPW + h) * 64 + lane;
+            v += v_at(o);
+            x += xw[o];
+        }
+        acc += (x[0] - v[0]) * (x[0] - v[0]) + (x[1] - v[1]) * (x[1] - v[1]);
+    }
     acc += __shfl_xor(acc, 16, 64);
     acc += __shfl_xor(acc, 32, 64);
     const long t = 16 * ft + (lane & 15);
@@ -662,21 +715,20 @@ __global__ __launch_bounds__(256) void k_wide64_err2(Wide64Args a, int TPW, int 
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-static const int WIDE64_TPW_SET[] = {5, 7, 9};
+static const int WIDE64_TPW_SET[] = {4, 5, 7, 8};      // whole bin tiles per wavefront; + one tile split over the four
 
 size_t wide_ctl_words(const Wide64Layout& f) { return 4 + 2 * (size_t)f.G; }
 
 bool wide64_supported(int M, int N, int T_, int dtype, int algo, int loss) {
-    return dtype == EVC_F64 && algo == EVC_ALGO_FACTORED && loss == EVC_LOSS_FROBENIUS && M > 208 && M <= 576 &&
+    return dtype == EVC_F64 && algo == EVC_ALGO_FACTORED && loss == EVC_LOSS_FROBENIUS && M > 208 && M <= 528 &&
            N >= 16 && T_ >= 1;
 }
 
 Wide64Layout wide64_layout(int M, int N, int T_, int n_cus, int c_req, int tpw_req) {
     Wide64Layout f{};
-    const int tpw = (M + 63) / 64;
-    f.TPW = 9;
+    f.TPW = 8;
     for (int v : WIDE64_TPW_SET)
-        if (v >= tpw && v >= tpw_req) { f.TPW = v; break; }
+        if (64 * v + 16 >= M && v >= tpw_req) { f.TPW = v; break; }
     f.NB = (N + 15) / 16;
     f.TT = (T_ + 15) / 16;
     f.G = (f.TT + 1) / 2;
@@ -687,8 +739,8 @@ Wide64Layout wide64_layout(int M, int N, int T_, int n_cus, int c_req, int tpw_r
     if (c > 64) c = 64;
     f.c = c;
     f.rmode = c > 4 ? 1 : 0;
-    const size_t gch = (size_t)4 * 2 * f.TPW * 256;       // doubles per group chunk
-    f.aw = (size_t)4 * (f.NB + 1) * 2 * f.TPW * 256 + (size_t)WIDE64_RING * 128;
+    const size_t gch = (size_t)4 * 2 * (f.TPW + 1) * 256;       // doubles per group chunk
+    f.aw = (size_t)4 * (f.NB + 1) * (4 * f.TPW + 1) * 128 + (size_t)WIDE64_RING * 128;
     f.xw = (size_t)f.G * gch;
     f.hw = (size_t)f.G * 2 * f.NB * 256;
     f.vpart = 2 * (size_t)f.G * f.c * gch;
@@ -705,7 +757,7 @@ Wide64Caps wide64_caps(int M, int N, int T_, int n_cus) {
     const int cmax = a.NB / 2 > 0 ? a.NB / 2 : 1;
     if (c_cap > cmax) c_cap = cmax;
     k.c_cap = c_cap;
-    const size_t gch = (size_t)4 * 2 * a.TPW * 256;
+    const size_t gch = (size_t)4 * 2 * (a.TPW + 1) * 256;
     k.aw = a.aw;
     k.xw = a.xw;
     k.hw = a.hw;
@@ -788,9 +840,10 @@ hipError_t wide_iterate(const Wide64Layout& f, const Wide64Buffers& b, const Utt
     if (n_cus <= 0) n_cus = 256;
     const unsigned grid = (unsigned)(tasks < n_cus ? tasks : n_cus);
     switch (f.TPW) {
+        case 4: return wide64_launch<4>(a, grid, s);
         case 5: return wide64_launch<5>(a, grid, s);
         case 7: return wide64_launch<7>(a, grid, s);
-        case 9: return wide64_launch<9>(a, grid, s);
+        case 8: return wide64_launch<8>(a, grid, s);
         default: return hipErrorInvalidValue;
     }
 }

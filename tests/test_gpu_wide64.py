@@ -1,9 +1,9 @@
-"""k_fused_wide64 (evc_wide64.hip): the fused FACTORED update for wide float64 spectra (208 < M <= 576 bins; the
+"""k_fused_wide64 (evc_wide64.hip): the fused FACTORED update for wide float64 spectra (208 < M <= 528 bins; the
 513-bin STFT magnitudes of BASELINE C3 / C5_513).
 
 The library routes batches of 160 ... 1000 frame tiles to it (4 to ~20 utterances: DESIGN.md section 5.2b, where it
-beats the two-contraction path); elsewhere the tuning bits select it: `fused_w >= 5` (the narrowest instance of 5, 7
-or 9 bin tiles per wavefront that holds M) and / or `fused_c` (exemplar ranges per frame group).  Every case enters through the C ABI
+beats the two-contraction path); elsewhere the tuning bits select it: `fused_w >= 4` (the narrowest instance of 4, 5,
+7 or 8 whole bin tiles per wavefront, plus one tile split over the four, that holds M) and / or `fused_c` (exemplar ranges per frame group).  Every case enters through the C ABI
 and is compared with the float64 oracle on the same inputs; tolerance 1e-9 relative (summation order only: the
 quotient is the correctly rounded division)."""
 import numpy as np
@@ -30,17 +30,17 @@ def sk_want(o, A, X, K, l1=0.0):
 
 
 @pytest.mark.parametrize("M,N,T,K,c,tpw", [
-    (513, 256, 64, 12, 0, 9), (513, 256, 64, 12, 1, 9), (513, 256, 40, 12, 2, 9), (513, 250, 50, 12, 3, 9),
-    (513, 1000, 100, 8, 0, 9), (513, 1000, 100, 8, 6, 9), (257, 300, 70, 10, 0, 5), (400, 512, 33, 10, 5, 7),
-    (576, 200, 17, 10, 0, 9), (209, 128, 32, 10, 2, 5), (320, 512, 130, 8, 8, 5), (448, 130, 1, 8, 0, 7),
-    (513, 17, 5, 6, 0, 9),
+    (513, 256, 64, 12, 0, 8), (513, 256, 64, 12, 1, 8), (513, 256, 40, 12, 2, 8), (513, 250, 50, 12, 3, 8),
+    (513, 1000, 100, 8, 0, 8), (513, 1000, 100, 8, 6, 8), (257, 300, 70, 10, 0, 4), (400, 512, 33, 10, 5, 7),
+    (528, 200, 17, 10, 0, 8), (209, 128, 32, 10, 2, 4), (320, 512, 130, 8, 8, 5), (448, 130, 1, 8, 0, 7),
+    (513, 17, 5, 6, 0, 8), (272, 256, 48, 8, 2, 4), (273, 256, 48, 8, 2, 5), (512, 256, 48, 8, 3, 8),
 ])
 def test_wide64_kernel_against_the_oracle(M, N, T, K, c, tpw):
     import exemplars_vc_amd as evc
     o = oracle()
     p = o.synth_problem(M, N, T, seed=M + N + T)
     got, info = evc.solve_activations(p["A"], p["X"], iters=K, eps_mode="zero_replace", init="sklearn", fused_c=c,
-                                      fused_w=5, info=True)
+                                      fused_w=4, info=True)
     assert info["kernel"] == "k_fused_wide64" and info["launches"] == 1 and info["redo"] == 0, info
     if c:
         assert info["members"] == min(c, max(1, ((N + 15) // 16) // 2)), info
@@ -71,7 +71,7 @@ def test_wide64_other_surfaces_and_convert(layout, eps_mode, eps):
     mode = {"add": o.EPS_ADD, "none": o.EPS_NONE, "clamp": o.EPS_CLAMP}[eps_mode]
     want = o.mu_solve(A, X, H0, 15, eps_mode=mode, eps=eps, algo="factored")
     tr = (lambda z: z) if layout == "bin_major" else (lambda z: np.ascontiguousarray(z.T))
-    H, Y = evc.convert(tr(A), tr(X), tr(B), tr(H0), layout=layout, iters=15, eps_mode=eps_mode, eps=eps, fused_w=5)
+    H, Y = evc.convert(tr(A), tr(X), tr(B), tr(H0), layout=layout, iters=15, eps_mode=eps_mode, eps=eps, fused_w=4)
     H, Y = (H, Y) if layout == "bin_major" else (H.T, Y.T)
     check(H, want)
     check(Y, B @ want)
@@ -86,7 +86,7 @@ def test_wide64_stop_rule_l1_and_utterances():
     offs = np.array([0, 37, 90], dtype=np.int32)
     H, info = evc.solve_activations(W_rows, X_rows, layout="frame_major", iters=120, eps_mode="zero_replace",
                                     init="sklearn", check_every=10, stop_rule="sklearn", tol=7e-3, info=True,
-                                    utt_offsets=offs, fused_w=5)
+                                    utt_offsets=offs, fused_w=4)
     assert info["kernel"] == "k_fused_wide64"
     n_its = []
     for u in range(2):
@@ -96,7 +96,7 @@ def test_wide64_stop_rule_l1_and_utterances():
         n_its.append(n_ref)
         check(H[a:b], act, rtol=1e-8)
     assert min(n_its) < 120, "the tolerance was meant to stop at least one utterance early"
-    got = evc.solve_activations(p["A"], p["X"], iters=10, eps_mode="zero_replace", init="sklearn", l1=0.05, fused_w=5)
+    got = evc.solve_activations(p["A"], p["X"], iters=10, eps_mode="zero_replace", init="sklearn", l1=0.05, fused_w=4)
     check(got, sk_want(o, p["A"], p["X"], 10, l1=0.05))
 
 
@@ -105,7 +105,7 @@ def test_wide64_repeatable_and_prepared_dictionary():
     import exemplars_vc_amd as evc
     o = oracle()
     p = o.synth_problem(513, 640, 150, seed=12)
-    kw = dict(iters=8, eps_mode="zero_replace", init="sklearn", fused_c=3, fused_w=5)
+    kw = dict(iters=8, eps_mode="zero_replace", init="sklearn", fused_c=3, fused_w=4)
     a = evc.solve_activations(p["A"], p["X"], **kw)
     b = evc.solve_activations(p["A"], p["X"], **kw)
     assert np.array_equal(a, b)
@@ -115,7 +115,7 @@ def test_wide64_repeatable_and_prepared_dictionary():
     assert np.array_equal(a, c)
     # the first 64 frames alone are the first 64 columns of the batch (frame groups are independent)
     d = evc.solve_activations(p["A"], np.ascontiguousarray(p["X"][:, :64]), iters=8, eps_mode="zero_replace",
-                              init_value=float(np.sqrt(p["X"].mean() / 640)), init="const", fused_c=3, fused_w=5)
+                              init_value=float(np.sqrt(p["X"].mean() / 640)), init="const", fused_c=3, fused_w=4)
     e = evc.solve_activations(p["A"], p["X"], iters=8, eps_mode="zero_replace",
-                              init_value=float(np.sqrt(p["X"].mean() / 640)), init="const", fused_c=3, fused_w=5)
+                              init_value=float(np.sqrt(p["X"].mean() / 640)), init="const", fused_c=3, fused_w=4)
     assert np.array_equal(d, e[:, :64])

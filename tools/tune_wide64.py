@@ -25,7 +25,7 @@ def main():
         Xd = torch.from_numpy(X).cuda()
         offs = np.arange(U + 1, dtype=np.int32) * 688
         row = []
-        for kw in (dict(), dict(fused_w=5)):
+        for kw in (dict(), dict(fused_w=4)):
             best = 1e9
             for rep in range(3):
                 torch.cuda.synchronize()

@@ -1,4 +1,4 @@
-"""Quick parity sweep of k_fused_wide64 (float64, 208 < M <= 576) against the oracle: shapes, exemplar-range counts,
+"""Quick parity sweep of k_fused_wide64 (float64, 208 < M <= 528) against the oracle: shapes, exemplar-range counts,
 eps modes, given H0, stop rule, synthesis; then the C3 shape timed (one utterance and, with `--batch`, sixteen).
 Run on the GPU box:  python tools/wide64_check.py [--batch]"""
 import os
@@ -23,7 +23,7 @@ def main():
     cases = [  # M, N, T, K, c
         (513, 256, 64, 20, 0), (513, 256, 64, 20, 1), (513, 256, 40, 20, 2), (513, 250, 50, 20, 3),
         (513, 1000, 100, 12, 0), (513, 1000, 100, 12, 6), (257, 300, 70, 15, 0), (400, 512, 33, 15, 5),
-        (576, 200, 17, 15, 0), (209, 128, 32, 15, 2), (320, 512, 130, 10, 8),
+        (528, 200, 17, 15, 0), (209, 128, 32, 15, 2), (320, 512, 130, 10, 8),
     ]
     for (M, N, T, K, c) in cases:
         p = o.synth_problem(M, N, T, seed=M + N + T)
@@ -31,7 +31,7 @@ def main():
         want = o.mu_solve(A, X, np.full((N, T), np.sqrt(X.mean() / N)), K, eps_mode=o.EPS_ZERO_REPLACE,
                           eps=float(np.finfo(np.float64).eps), algo="factored")
         t0 = time.time()
-        got, info = evc.solve_activations(A, X, iters=K, eps_mode="zero_replace", init="sklearn", fused_c=c, fused_w=5, info=True)
+        got, info = evc.solve_activations(A, X, iters=K, eps_mode="zero_replace", init="sklearn", fused_c=c, fused_w=4, info=True)
         dt = time.time() - t0
         r = rel(got, want)
         ok = r < 1e-9 and info["kernel"] == "k_fused_wide64"
@@ -45,7 +45,7 @@ def main():
     want = o.mu_solve(A, X, H0, 30, eps_mode=o.EPS_ADD, eps=1e-9, algo="factored")
     for lay in ("bin_major", "frame_major"):
         tr = (lambda z: z) if lay == "bin_major" else (lambda z: np.ascontiguousarray(z.T))
-        H, Y = evc.convert(tr(A), tr(X), tr(B), tr(H0), layout=lay, iters=30, eps_mode="add", fused_w=5)
+        H, Y = evc.convert(tr(A), tr(X), tr(B), tr(H0), layout=lay, iters=30, eps_mode="add", fused_w=4)
         H, Y = (H, Y) if lay == "bin_major" else (H.T, Y.T)
         r, ry = rel(H, want), rel(Y, B @ want)
         ok = r < 1e-9 and ry < 1e-9
@@ -55,7 +55,7 @@ def main():
     X_rows, W_rows = np.ascontiguousarray(X.T), np.ascontiguousarray(A.T)
     act, n_ref, _ = o.sklearn_mu_fixed_dictionary(X_rows, W_rows, 150, 1e-3)
     H, info = evc.solve_activations(W_rows, X_rows, layout="frame_major", iters=150, eps_mode="zero_replace",
-                                    init="sklearn", check_every=10, stop_rule="sklearn", tol=1e-3, info=True, fused_w=5)
+                                    init="sklearn", check_every=10, stop_rule="sklearn", tol=1e-3, info=True, fused_w=4)
     r = rel(H, act)
     ok = r < 1e-8 and int(info["n_iter"][0]) == n_ref and info["kernel"] == "k_fused_wide64"
     bad += not ok
@@ -64,7 +64,7 @@ def main():
     offs = np.array([0, 37, 90], dtype=np.int32)
     H2, info2 = evc.solve_activations(W_rows, X_rows, layout="frame_major", iters=150, eps_mode="zero_replace",
                                       init="sklearn", check_every=10, stop_rule="sklearn", tol=1e-3, info=True,
-                                      utt_offsets=offs, fused_w=5)
+                                      utt_offsets=offs, fused_w=4)
     for u in range(2):
         a, b = offs[u], offs[u + 1]
         actu, nu, _ = o.sklearn_mu_fixed_dictionary(X_rows[a:b], W_rows, 150, 1e-3)
@@ -87,7 +87,7 @@ def main():
             torch.cuda.synchronize()
             t0 = time.time()
             H, info = evc.solve_activations(Ad, Xd, iters=K, eps_mode="zero_replace", init="sklearn", info=True,
-                                            utt_offsets=offs if U > 1 else None, fused_w=5)
+                                            utt_offsets=offs if U > 1 else None, fused_w=4)
             torch.cuda.synchronize()
             dt = time.time() - t0
         fl = K * (4.0 * M * N + 3.0 * N) * T
