@@ -524,10 +524,10 @@ WideWs<T> carve_wide(void* base, const Dims& d, int n_slots, int n_cus, bool wit
 // 334 / 457 for sixteen (profiles/r03_wide_tuning.md).  The tuning bits (ranges, wavefronts) force the fused
 // kernel at any size.
 constexpr int WIDE_MIN_TILES = 300;
-// float64 (k_fused_wide64), measured at M = 513, N = 8192 (tools/tune_wide64.py; fraction of the fp64 matrix peak, fused
-// against two contractions): 2 utterances 0.32 / 0.58, 4: 0.62 / 0.59, 6: 0.62 / 0.50, 8: 0.64 / 0.62, 16: 0.64 / 0.62,
-// 32: 0.65 / 0.68, 64: 0.65 / 0.72 - the fused kernel serves the batches in between
-constexpr int WIDE64_MIN_TILES = 160, WIDE64_MAX_TILES = 1000;
+// float64 (k_fused_wide64), measured at M = 513, N = 8192 (tools/tune_wide64.py, K = 60; fraction of the fp64 matrix peak,
+// fused against two contractions): 2 utterances 0.32 / 0.58, 4: 0.63 / 0.59 (bench.py at K = 200: 0.57), 6: 0.63 / 0.50,
+// 8: 0.66 / 0.62, 16: 0.67 / 0.62, 32: 0.67 / 0.68, 64: 0.67 / 0.72 - the fused kernel serves the batches in between
+constexpr int WIDE64_MIN_TILES = 240, WIDE64_MAX_TILES = 1000;
 bool use_wide(int M, int N, int T_, int dtype, int algo, int loss, int reserved) {
     if (reserved & EVC_FLAG_NO_FUSED) return false;
     const bool forced = ((reserved >> 8) & 0xff) != 0 || ((reserved >> 16) & 0xf) != 0;

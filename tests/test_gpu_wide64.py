@@ -1,7 +1,7 @@
 """k_fused_wide64 (evc_wide64.hip): the fused FACTORED update for wide float64 spectra (208 < M <= 528 bins; the
 513-bin STFT magnitudes of BASELINE C3 / C5_513).
 
-The library routes batches of 160 ... 1000 frame tiles to it (4 to ~20 utterances: DESIGN.md section 5.2b, where it
+The library routes batches of 240 ... 1000 frame tiles to it (6 to ~20 utterances: DESIGN.md section 5.2b, where it
 beats the two-contraction path); elsewhere the tuning bits select it: `fused_w >= 4` (the narrowest instance of 4, 5,
 7 or 8 whole bin tiles per wavefront, plus one tile split over the four, that holds M) and / or `fused_c` (exemplar ranges per frame group).  Every case enters through the C ABI
 and is compared with the float64 oracle on the same inputs; tolerance 1e-9 relative (summation order only: the
@@ -49,10 +49,10 @@ def test_wide64_kernel_against_the_oracle(M, N, T, K, c, tpw):
 
 
 def test_wide64_routing_by_batch_size():
-    """(evc_api.hip, use_wide: the fused kernel serves 160 ... 1000 frame tiles, where it beats the two contractions)"""
+    """(evc_api.hip, use_wide: the fused kernel serves 240 ... 1000 frame tiles, where it beats the two contractions)"""
     import exemplars_vc_amd as evc
     o = oracle()
-    for T, kernel in ((64, "k_gemm_nt"), (2700, "k_fused_wide64")):
+    for T, kernel in ((64, "k_gemm_nt"), (4000, "k_fused_wide64")):
         p = o.synth_problem(513, 256, T, seed=T)
         got, info = evc.solve_activations(p["A"], p["X"], iters=4, eps_mode="zero_replace", init="sklearn", info=True)
         assert info["kernel"] == kernel, info
