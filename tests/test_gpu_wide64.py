@@ -78,24 +78,28 @@ def test_wide64_other_surfaces_and_convert(layout, eps_mode, eps):
 
 
 def test_wide64_stop_rule_l1_and_utterances():
-    """scikit-learn's stop rule evaluated between launches on the published V; frozen utterances; l1"""
+    """scikit-learn's stop rule evaluated between launches on the published V; an utterance that stops early is
+    frozen while its neighbour in the same frame group goes on (37 frames: the boundary cuts a group of 32); l1"""
     import exemplars_vc_amd as evc
     o = oracle()
     p = o.synth_problem(513, 384, 90, seed=9)
-    X_rows, W_rows = np.ascontiguousarray(p["X"].T), np.ascontiguousarray(p["A"].T)
+    A, X = p["A"], p["X"].copy()
+    rng = np.random.default_rng(3)
+    X[:, :37] = A[:, rng.integers(0, 384, 37)] * rng.random(37) + 1e-9        # near-exemplar frames: converge early
+    X_rows, W_rows = np.ascontiguousarray(X.T), np.ascontiguousarray(A.T)
     offs = np.array([0, 37, 90], dtype=np.int32)
     H, info = evc.solve_activations(W_rows, X_rows, layout="frame_major", iters=120, eps_mode="zero_replace",
-                                    init="sklearn", check_every=10, stop_rule="sklearn", tol=7e-3, info=True,
+                                    init="sklearn", check_every=10, stop_rule="sklearn", tol=5e-3, info=True,
                                     utt_offsets=offs, fused_w=4)
     assert info["kernel"] == "k_fused_wide64"
     n_its = []
     for u in range(2):
         a, b = offs[u], offs[u + 1]
-        act, n_ref, _ = o.sklearn_mu_fixed_dictionary(X_rows[a:b], W_rows, 120, 7e-3)
+        act, n_ref, _ = o.sklearn_mu_fixed_dictionary(X_rows[a:b], W_rows, 120, 5e-3)
         assert int(info["n_iter"][u]) == n_ref
         n_its.append(n_ref)
         check(H[a:b], act, rtol=1e-8)
-    assert min(n_its) < 120, "the tolerance was meant to stop at least one utterance early"
+    assert n_its[0] < n_its[1], "the first utterance was meant to stop before the second"
     got = evc.solve_activations(p["A"], p["X"], iters=10, eps_mode="zero_replace", init="sklearn", l1=0.05, fused_w=4)
     check(got, sk_want(o, p["A"], p["X"], 10, l1=0.05))
 
