@@ -231,6 +231,25 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
         bool live = false;
         float h0v = 0.f;
         if (on) {
+            const int t = ft * 16 + i16;
+            if (t < a.T_) {
+                const int ut = a.frame_utt[t];
+                if (ut >= 0) {
+                    live = a.active[ut] != 0;
+                    h0v = (float)a.h0[ut];
+                }
+            }
+        }
+        // A frame group whose utterances have all stopped (or that is padding) does not sweep: its H stays, and so does
+        // V' = A H - the task republishes the partial it published one iteration ago (the same bits a sweep would give).
+        const bool idle = it > 0 && !__syncthreads_or(live ? 1 : 0);
+        if (on && idle) {
+            const __amdgpu_buffer_rsrc_t rv =
+                make_rsrc(a.Vpart + ((((size_t)((par ^ 1u) * a.G + g) * c + e) * W + w)) * (TILE_B / 4), TILE_B);
+#pragma unroll
+            for (int u = 0; u < MT; ++u) Vn[u] = ld_sc1(rv, (u * 64 + lane) * 16u);
+        }
+        if (on && !idle) {
             const f32x4* xt = reinterpret_cast<const f32x4*>(a.Xw) + (size_t)ft * (MT * 64) + lane;
             if (it == 0) {
 #pragma unroll
@@ -259,14 +278,6 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
                     for (int r = 0; r < 4; ++r) Vin[u][r] = x[r] / (Vin[u][r] < a.eps ? a.eps : Vin[u][r]);
                 }
             }
-            const int t = ft * 16 + i16;
-            if (t < a.T_) {
-                const int ut = a.frame_utt[t];
-                if (ut >= 0) {
-                    live = a.active[ut] != 0;
-                    h0v = (float)a.h0[ut];
-                }
-            }
         }
         const __amdgpu_buffer_rsrc_t rh = make_rsrc(a.Hw + (size_t)(on ? ft : 0) * a.NB * 256, (unsigned)a.NB * 1024u);
         const __amdgpu_buffer_rsrc_t rp = make_rsrc(a.Pw + (size_t)(on ? ft : 0) * a.NB * 256, (unsigned)a.NB * 1024u);
@@ -275,7 +286,7 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
         const float c0 = it == 0 ? 0.f : a.l1 + (a.mode == EVC_EPS_ADD ? a.eps : 0.f);
         const int n_edge = (a.N & 15) ? a.NB - 1 : -1;           // the block that reaches into the zero padding
         f32x4 hC = f32x4{0, 0, 0, 0}, pC = hC, hN = hC, pN = hC;
-        if (on && nb > 0) {
+        if (on && nb > 0 && !idle) {
             if (load_h) hC = ld_sc1(rh, (j0 * 64 + lane) * 16u);
             if (load_p) pC = ld_sc1(rp, (j0 * 64 + lane) * 16u);
         }
@@ -414,7 +425,7 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
         const char* s2P = nullptr;         // ... and that block's V' image
         bool qa2 = false;                  // q0 / q1 hold the first fragment pair of that image
         int st = 0;                        // LDS stage of block i
-        for (int i = 0; i < nb; ++i) {
+        for (int i = 0; i < (idle ? 0 : nb); ++i) {
             const int jb = j0 + i, stn = st == NSTAGE - 1 ? 0 : st + 1;
             const char* sb = smem + (no_dma ? 0 : st) * IMG;
             const char* s2 = sb + MT * 1024;

@@ -273,6 +273,36 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
         if (it > 0 && !wait_for(a.rmode ? a.done_r + g : a.done + g, c * (unsigned)it)) break;
         W64STAMP(1);
 
+        // the quarter of H / P this wavefront owns: frame tile 2 g + ftq, registers 2 xq, 2 xq + 1
+        const int ft = 2 * g + ftq;
+        bool live = false;
+        double h0v = 0.0;
+        {
+            const int t = ft * 16 + i16;
+            if (t < a.T_) {
+                const int ut = a.frame_utt[t];
+                if (ut >= 0) {
+                    live = a.active[ut] != 0;
+                    h0v = a.h0[ut];
+                }
+            }
+        }
+        // A frame group whose utterances have all stopped (or that is padding) does not sweep: its H stays, and so does
+        // V' = A H - the task republishes the partial it published one iteration ago (the same bits a sweep would give).
+        if (it > 0 && !__syncthreads_or(live ? 1 : 0)) {
+            const __amdgpu_buffer_rsrc_t rsrc = rsrc64(a.Vpart + (((size_t)((par ^ 1u) * a.G + g) * c + e) * 4 + w) * (WCH / 8), WCH);
+            const __amdgpu_buffer_rsrc_t rdst = rsrc64(a.Vpart + (((size_t)(par * a.G + g) * c + e) * 4 + w) * (WCH / 8), WCH);
+#pragma unroll 4
+            for (unsigned o = lane16; o < WCH; o += 1024u) st2_sc1(rdst, o, 0, ld2_sc1(rsrc, o, 0));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the ring's loads of this task too)
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_fetch_add(a.done + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_ctl[0] = nxt;
+            }
+            __syncthreads();
+            continue;
+        }
         // V of this wavefront's bins, both frame tiles
         f64x4 Vin[2][TPW], Vn[2][TPW], Vo[2];
         double Vodd[2] = {0.0, 0.0};                   // rows 4 w + q of the extra tile of V (B operand of its k-step w)
@@ -314,20 +344,6 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
 #pragma unroll
                 for (int k = 0; k < TPW; ++k) Vn[f][k] = f64x4{0, 0, 0, 0};
                 Vo[f] = f64x4{0, 0, 0, 0};
-            }
-        }
-        // the quarter of H / P this wavefront owns: frame tile 2 g + ftq, registers 2 xq, 2 xq + 1
-        const int ft = 2 * g + ftq;
-        bool live = false;
-        double h0v = 0.0;
-        {
-            const int t = ft * 16 + i16;
-            if (t < a.T_) {
-                const int ut = a.frame_utt[t];
-                if (ut >= 0) {
-                    live = a.active[ut] != 0;
-                    h0v = a.h0[ut];
-                }
             }
         }
         const __amdgpu_buffer_rsrc_t rh = rsrc64(a.Hw + (size_t)ft * a.NB * 256, (unsigned)a.NB * 2048u);
