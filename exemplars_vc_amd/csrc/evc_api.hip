@@ -180,7 +180,7 @@ Workspace<T> carve(void* base, const Dims& d, int algo, int n_slots, bool fused,
     w.err2 = c.take<double>(d.Tp);
     w.u.frame_utt = c.take<int>(d.Tp);
     w.u.offsets = c.take<int>(d.n_utt + 1);
-    w.u.active = c.take<int>(d.n_utt);
+    w.u.active = c.take<int>(d.n_utt + 1);
     w.u.n_iter = c.take<int>(d.n_utt);
     w.u.err_init = c.take<double>(d.n_utt);
     w.u.err_prev = c.take<double>(d.n_utt);
@@ -507,7 +507,7 @@ WideWs<T> carve_wide(void* base, const Dims& d, int n_slots, int n_cus, bool wit
     w.err2 = c.take<double>(d.Tp);
     w.u.frame_utt = c.take<int>(d.Tp);
     w.u.offsets = c.take<int>(d.n_utt + 1);
-    w.u.active = c.take<int>(d.n_utt);
+    w.u.active = c.take<int>(d.n_utt + 1);
     w.u.n_iter = c.take<int>(d.n_utt);
     w.u.err_init = c.take<double>(d.n_utt);
     w.u.err_prev = c.take<double>(d.n_utt);
@@ -771,6 +771,10 @@ int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int 
     MuEpilogue<T> ep;
     ep.P = w.Pt; ep.frame_utt = w.u.frame_utt; ep.active = w.u.active; ep.ldh = d.Np;
     ep.N = N; ep.T_ = T_; ep.eps_mode = o.eps_mode; ep.eps = (T)o.eps; ep.l1 = (T)o.l1; ep.kl = kl ? 1 : 0;
+    // Once the stop rules have stopped every utterance the launches still queued return at once (the host does not
+    // read the flags back: the call stays asynchronous).  In-place path only: GRAM swaps its two H buffers per launch.
+    const int* gate = (!gram && o.check_every > 0 && o.stop_rule != EVC_STOP_NONE) ? w.u.active + n_utt : nullptr;
+    ep.gate = gate;
 
     inf->kernel = gemm_kernel_id<T>();
     inf->members = 1;
@@ -786,7 +790,7 @@ int solve_typed(const void* A_, int lda, const void* X_, int ldx, void* H_, int 
             HIP_TRY(gemm_nt_mu<T>(Hc, d.Np, w.G, d.Np, Hn, d.Tp, d.Np, d.Np, ep, s));
             T* tmp = Hc; Hc = Hn; Hn = tmp;
         } else {
-            if (!v_valid) HIP_TRY(gemm_nt<T>(Hc, d.Np, w.Am, d.Np, w.Vt, d.Mj, d.Tp, d.Mj, d.Np, s, w.Vsplit, w.vsplit_elems, nullptr, d.Mk));
+            if (!v_valid) HIP_TRY(gemm_nt<T>(Hc, d.Np, w.Am, d.Np, w.Vt, d.Mj, d.Tp, d.Mj, d.Np, s, w.Vsplit, w.vsplit_elems, nullptr, d.Mk, gate));
             ep.Hin = Hc;
             if (kl) {                     // H' = H (.) (X (/) max(V, eps)) (A / colsum)   sklearn _nmf.py:556-606
                 HIP_TRY(kl_ratio<T>(w.Xt, d.Mk, w.Vt, d.Mj, M, d.Tp, o.eps, w.Rt, d.Mk, s));

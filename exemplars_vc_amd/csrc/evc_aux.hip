@@ -81,6 +81,11 @@ __global__ void k_utt_setup(UttState u, int n_utt, int T_, int Tp, int iters) {
         u.err_prev[i] = 0.0;
         u.h0[i] = 0.0;
     }
+    if (gid == 0) {                   // how many utterances are active: the gate of the generic path's kernels
+        int n = 0;
+        for (int i = 0; i < n_utt; ++i) n += (u.offsets[i + 1] > u.offsets[i]) ? 1 : 0;
+        u.active[n_utt] = n;
+    }
     const double nan = __longlong_as_double(0x7ff8000000000000ULL);
     for (long i = gid; i < (long)n_utt * u.n_slots; i += stride) u.trace[i] = nan;
 }
@@ -305,6 +310,7 @@ __global__ __launch_bounds__(256) void k_utt_check(const double* __restrict__ er
     }
     if (stop) {
         u.active[id] = 0;
+        atomicSub(&u.active[gridDim.x], 1);
         u.n_iter[id] = c * check_every;
     } else {
         u.err_prev[id] = err;

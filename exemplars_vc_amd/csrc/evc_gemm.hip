@@ -32,6 +32,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_gemm_nt(
     int Kd, MuEpilogue<T> ep, long slab, int jv) {
     // (An XCD-aware renumbering of the blocks, as in k_gemm2, was measured here and dropped: no change at C3, where
     // it cut each XCD's share of the dictionary to one eighth, and 18 % slower on Griffin-Lim's 84-tile products.)
+    if (ep.gate && *ep.gate == 0) return;      // (uniform: every utterance has stopped)
     const unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     // split-K: block z owns k in [z Kd, (z+1) Kd) and writes its partial product to slab z
     L += (long)bz * Kd;
@@ -202,18 +203,18 @@ static hipError_t launch_nt(const T* L, int ldl, const T* R, int ldr, T* C, int 
 // C = sum_z part[z]   (fixed order: bitwise reproducible)
 template <typename T>
 __global__ __launch_bounds__(256) void k_sum_slabs(const T* __restrict__ part, long slab, int splits, long n,
-                                                   T* __restrict__ C) {
+                                                   T* __restrict__ C, const int* gate) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n || (gate && *gate == 0)) return;
     T acc = part[i];
     for (int z = 1; z < splits; ++z) acc += part[z * slab + i];
     C[i] = acc;
 }
 
 template <typename T>
-hipError_t sum_slabs(const T* part, long slab, int splits, T* C, hipStream_t s) {
+hipError_t sum_slabs(const T* part, long slab, int splits, T* C, hipStream_t s, const int* gate) {
     hipLaunchKernelGGL((k_sum_slabs<T>), dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, s, part, slab, splits,
-                       slab, C);
+                       slab, C, gate);
     return hipGetLastError();
 }
 
@@ -233,7 +234,7 @@ template <typename T> static bool use_gemm2() {
 
 template <typename T>
 hipError_t gemm_nt(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int I, int J, int Kd,
-                   hipStream_t s, T* scratch, size_t scratch_elems, int* splits_out, int j_valid) {
+                   hipStream_t s, T* scratch, size_t scratch_elems, int* splits_out, int j_valid, const int* gate) {
     if (splits_out) *splits_out = 0;
     if (I <= 0 || J <= 0) return hipSuccess;
     if (use_gemm2<T>() && gemm2_ok<T>(L, ldl, R, ldr, C, ldc, I, J, Kd)) {
@@ -241,10 +242,11 @@ hipError_t gemm_nt(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int 
         if (scratch && (hipGetDevice(&dev) != hipSuccess ||
                         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess))
             cus = 0;
-        return gemm2<T>(L, ldl, R, ldr, C, ldc, I, J, Kd, s, scratch, scratch_elems, splits_out, cus, j_valid);
+        return gemm2<T>(L, ldl, R, ldr, C, ldc, I, J, Kd, s, scratch, scratch_elems, splits_out, cus, j_valid, gate);
     }
     if (I % 64 || J % 64 || Kd % KS || Kd <= 0) return hipErrorInvalidValue;
     MuEpilogue<T> ep{};
+    ep.gate = gate;
     // few output tiles (one utterance): 64x64 tiles put 2-4x more workgroups on the 256 CUs, and a long
     // contraction is additionally split over blockIdx.z into slabs of partial products (summed in order)
     const long blocks = (long)(I / 64) * (J / 64);
@@ -268,7 +270,7 @@ hipError_t gemm_nt(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int 
             return hipSuccess;
         }
         hipLaunchKernelGGL((k_sum_slabs<T>), dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, s, scratch, slab, splits,
-                           slab, C);
+                           slab, C, gate);
         return hipGetLastError();
     }
     if (I % 128) {      // short batches are padded to 64 frames only: 64-row blocks
@@ -467,10 +469,10 @@ hipError_t synth_skinny(const T* H, long hst, long hsn, const T* B, long bsn, lo
 }
 
 #define EVC_INST(T)                                                                                  \
-    template hipError_t gemm_nt<T>(const T*, int, const T*, int, T*, int, int, int, int, hipStream_t, T*, size_t, int*, int); \
+    template hipError_t gemm_nt<T>(const T*, int, const T*, int, T*, int, int, int, int, hipStream_t, T*, size_t, int*, int, const int*); \
     template hipError_t gemm_nt_mu<T>(const T*, int, const T*, int, T*, int, int, int,                \
                                       const MuEpilogue<T>&, hipStream_t);                            \
-    template hipError_t sum_slabs<T>(const T*, long, int, T*, hipStream_t);                          \
+    template hipError_t sum_slabs<T>(const T*, long, int, T*, hipStream_t, const int*);                          \
     template hipError_t gemm_strided<T>(const T*, long, long, const T*, long, long, T*, long, long,  \
                                         int, int, int, hipStream_t);                                  \
     template hipError_t synth_skinny<T>(const T*, long, long, const T*, long, long, T*, long, long,  \

@@ -77,6 +77,7 @@ __global__ __launch_bounds__((BF / WF) * (BR / WR) * 64, MINW) void k_gemm2(
     // that the R blocks of one frame block are neighbours in time on ONE XCD: H then crosses the fabric once
     // instead of once per R block.  The update kernel keeps the plain order: there an XCD sees every 8th exemplar
     // block only, i.e. one eighth of the dictionary, and the shared operand (V) is small.
+    if (ep.gate && *ep.gate == 0) return;      // (uniform: every utterance has stopped)
     unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
     if (!MU) {
         const unsigned gx = gridDim.x, gxy = gx * gridDim.y, total = gxy * gridDim.z;
@@ -405,9 +406,10 @@ static double round_eff(long wg, long slots) { return (double)wg / (double)(((wg
 // C = L R^T.  With `scratch` (and ldc == J) a short grid is split over k into slabs; see gemm_nt for splits_out.
 template <typename T>
 hipError_t gemm2(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int I, int J, int Kd, hipStream_t s,
-                 T* scratch, size_t scratch_elems, int* splits_out, int n_cus, int jv) {
+                 T* scratch, size_t scratch_elems, int* splits_out, int n_cus, int jv, const int* gate) {
     if (splits_out) *splits_out = 0;
     MuEpilogue<T> ep{};
+    ep.gate = gate;
     if (n_cus <= 0) n_cus = 256;
     // 64 x 128 blocks (three per CU) when R has a multiple of 128 rows and the grid fills the CUs; 64 x 64 blocks
     // (four per CU) otherwise: a grid of less than one round runs as long as ONE workgroup does, so the smallest
@@ -444,7 +446,7 @@ hipError_t gemm2(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int I,
         *splits_out = splits;
         return hipSuccess;
     }
-    return sum_slabs<T>(scratch, slab, splits, C, s);
+    return sum_slabs<T>(scratch, slab, splits, C, s, gate);
 }
 
 // the same contraction with the multiplicative update as epilogue: Hout = mu(Hin, P, L R^T)
@@ -474,7 +476,7 @@ hipError_t gemm2_mu(const T* L, int ldl, const T* R, int ldr, T* Hout, int I, in
 #define EVC_INST2(T)                                                                                              \
     template bool gemm2_ok<T>(const T*, int, const T*, int, const T*, int, int, int, int);                        \
     template hipError_t gemm2<T>(const T*, int, const T*, int, T*, int, int, int, int, hipStream_t, T*, size_t,  \
-                                 int*, int, int);                                                                   \
+                                 int*, int, int, const int*);                                                       \
     template hipError_t gemm2_mu<T>(const T*, int, const T*, int, T*, int, int, int, const MuEpilogue<T>&, hipStream_t);
 EVC_INST2(double)
 EVC_INST2(float)

@@ -57,7 +57,7 @@ __device__ __forceinline__ T mu_update(T h, T p, T d, int eps_mode, T eps, T l1)
 struct UttState {
     int* frame_utt;      // [Tp]  utterance index of each frame (padding frames: -1)
     int* offsets;        // [n_utt+1]
-    int* active;         // [n_utt]
+    int* active;         // [n_utt + 1]: per utterance; [n_utt]: how many are active (the gate of the generic path's kernels)
     int* n_iter;         // [n_utt]
     double* err_init;    // [n_utt]
     double* err_prev;    // [n_utt]
@@ -76,6 +76,7 @@ template <typename T> struct MuEpilogue {
     int eps_mode;
     T eps, l1;
     int kl;              // 1: Hout = Hin * acc (the KL numerator over a pre-scaled dictionary); P unused
+    const int* gate;     // optional: the kernel returns at once when *gate == 0 (no utterance is active any more)
 };
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
@@ -86,7 +87,9 @@ static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 template <typename T>
 hipError_t gemm_nt(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int I, int J, int Kd,
                    hipStream_t s, T* scratch = nullptr, size_t scratch_elems = 0, int* splits_out = nullptr,
-                   int j_valid = 0);
+                   int j_valid = 0, const int* gate = nullptr);
+// gate: optional device word; the launched kernels return at once when it is 0 (the stop rules have stopped every
+// utterance: the launches the host has still queued cost a few microseconds each instead of a contraction)
 // j_valid: rows of R from j_valid on are known to be zero (padding up to the block width); their products are skipped
 // splits_out: when the contraction was split over k into slabs in `scratch` (slab z at scratch + z * I * ldc),
 // *splits_out = their number and C is NOT written - the caller's next kernel sums them in order; else 0.
@@ -100,13 +103,13 @@ template <typename T>
 bool gemm2_ok(const T* L, int ldl, const T* R, int ldr, const T* C, int ldc, int I, int J, int Kd);
 template <typename T>
 hipError_t gemm2(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int I, int J, int Kd, hipStream_t s,
-                 T* scratch, size_t scratch_elems, int* splits_out, int n_cus, int j_valid);
+                 T* scratch, size_t scratch_elems, int* splits_out, int n_cus, int j_valid, const int* gate = nullptr);
 template <typename T>
 hipError_t gemm2_mu(const T* L, int ldl, const T* R, int ldr, T* Hout, int I, int J, int Kd,
                     const MuEpilogue<T>& ep, hipStream_t s);
 // C = sum_z part[z * slab + .]  (fixed order)
 template <typename T>
-hipError_t sum_slabs(const T* part, long slab, int splits, T* C, hipStream_t s);
+hipError_t sum_slabs(const T* part, long slab, int splits, T* C, hipStream_t s, const int* gate = nullptr);
 // Bounds-checked general-stride contraction on caller memory (used by evc_synthesize):
 // C[i*csi + j*csj] = sum_k L[i*lsi + k*lsk] * R[j*rsj + k*rsk]
 template <typename T>

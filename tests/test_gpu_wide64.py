@@ -123,3 +123,33 @@ def test_wide64_repeatable_and_prepared_dictionary():
     e = evc.solve_activations(p["A"], p["X"], iters=8, eps_mode="zero_replace",
                               init_value=float(np.sqrt(p["X"].mean() / 640)), init="const", fused_c=3, fused_w=4)
     assert np.array_equal(d, e[:, :64])
+
+
+@pytest.mark.parametrize("dtype,M,kernel", [(np.float64, 513, "k_gemm_nt"), (np.float32, 201, "k_gemm2")])
+def test_generic_path_gate_after_every_utterance_stopped(dtype, M, kernel):
+    """the two-contraction path: once the stop rule has stopped every utterance the launches still queued return at
+    once (evc_api.hip, `gate`); an utterance that goes on keeps the gate open for the whole batch"""
+    import exemplars_vc_amd as evc
+    o = oracle()
+    p = o.synth_problem(M, 256, 90, seed=21)
+    A, X = p["A"].astype(dtype), p["X"].astype(dtype).copy()
+    rng = np.random.default_rng(3)
+    X[:, :37] = (A[:, rng.integers(0, 256, 37)] * rng.random(37).astype(dtype) + dtype(1e-9)).astype(dtype)
+    X_rows, W_rows = np.ascontiguousarray(X.T), np.ascontiguousarray(A.T)
+    X64, W64 = X_rows.astype(np.float64), W_rows.astype(np.float64)
+    eps32 = dict(rtol=2e-3, atol=1e-6) if dtype == np.float32 else dict(rtol=1e-8, atol=1e-300)
+    for offs in (np.array([0, 37], dtype=np.int32), np.array([0, 37, 90], dtype=np.int32)):
+        T = int(offs[-1])
+        H, info = evc.solve_activations(W_rows, X_rows[:T], layout="frame_major", iters=120, eps_mode="zero_replace",
+                                        init="sklearn", check_every=10, stop_rule="sklearn", tol=5e-3, info=True,
+                                        utt_offsets=offs)
+        assert info["kernel"] == kernel, info
+        for u in range(len(offs) - 1):
+            a, b = offs[u], offs[u + 1]
+            act, n_ref, _ = o.sklearn_mu_fixed_dictionary(X64[a:b], W64, 120, 5e-3)
+            if dtype == np.float64:
+                assert int(info["n_iter"][u]) == n_ref
+            got = H[a:b].astype(np.float64)
+            if int(info["n_iter"][u]) == n_ref:
+                np.testing.assert_allclose(got, act, atol=eps32["atol"] * float(np.abs(act).max()) if dtype == np.float32 else 0.0,
+                                           rtol=eps32["rtol"])
