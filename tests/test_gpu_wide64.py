@@ -153,3 +153,42 @@ def test_generic_path_gate_after_every_utterance_stopped(dtype, M, kernel):
             if int(info["n_iter"][u]) == n_ref:
                 np.testing.assert_allclose(got, act, atol=eps32["atol"] * float(np.abs(act).max()) if dtype == np.float32 else 0.0,
                                            rtol=eps32["rtol"])
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_wide64_random_shapes_against_the_two_contraction_path(seed):
+    """Differential test over seeded random shapes: the fused float64 kernel (random ranges per group, every instance)
+    against the two-contraction path on the same call - ragged utterances, exemplar counts that are not multiples of
+    16, bin counts on both sides of the whole-tile boundaries, both layouts, the synthesis, error traces over several
+    launches, correctly rounded quotients on request."""
+    import exemplars_vc_amd as evc
+    o = oracle()
+    rng = np.random.default_rng(700 + seed)
+    M = int(rng.choice([int(rng.integers(209, 529)), 64 * int(rng.integers(4, 9)) + int(rng.integers(0, 17)), 513, 257]))
+    M = min(max(M, 209), 528)
+    N = int(rng.choice([int(rng.integers(40, 300)), int(rng.integers(300, 1200)), 16 * int(rng.integers(8, 60))]))
+    lens = [int(rng.integers(1, 150)) for _ in range(int(rng.integers(1, 6)))]
+    T = sum(lens)
+    p = o.synth_problem(M, N, T, seed=1300 + seed)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+    K = int(rng.integers(1, 14))
+    layout = "frame_major" if seed % 2 else "bin_major"
+    tr = (lambda a: np.ascontiguousarray(a.T)) if layout == "frame_major" else (lambda a: np.ascontiguousarray(a))
+    kw = dict(layout=layout, iters=K, eps_mode=["zero_replace", "add", "clamp", "none"][seed % 4],
+              init=["sklearn", "const"][seed % 2], utt_offsets=offs, exact_div=bool(seed % 3 == 0))
+    if kw["init"] == "const":
+        kw["init_value"] = 0.21
+    if seed % 4 == 3:
+        kw.update(check_every=4, info=True)
+    if seed % 5 == 1:
+        kw.update(l1=0.03)
+    c = int(rng.integers(0, 9))
+    got = evc.convert(tr(p["A"]), tr(p["X"]), tr(p["B"]), fused_c=c, fused_w=4, **kw)
+    want = evc.convert(tr(p["A"]), tr(p["X"]), tr(p["B"]), fused=False, **kw)
+    for g, wv, name in zip(got[:2], want[:2], ("H", "Y")):
+        np.testing.assert_allclose(g, wv, rtol=1e-9, atol=1e-12 * float(np.abs(wv).max()),
+                                   err_msg=f"seed {seed} M={M} N={N} lens={lens} K={K} c={c} {layout}: {name}")
+    if seed % 4 == 3:
+        assert got[2]["kernel"] == "k_fused_wide64" and want[2]["kernel"] == "k_gemm_nt"
+        np.testing.assert_allclose(got[2]["err"], want[2]["err"], rtol=1e-9, atol=1e-12 * float(np.linalg.norm(p["X"])),
+                                   equal_nan=True)
