@@ -34,9 +34,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_gemm_nt(
     // it cut each XCD's share of the dictionary to one eighth, and 18 % slower on Griffin-Lim's 84-tile products.)
     if (ep.gate && *ep.gate == 0) return;      // (uniform: every utterance has stopped)
     const unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    // split-K: block z owns k in [z Kd, (z+1) Kd) and writes its partial product to slab z
-    L += (long)bz * Kd;
-    R += (long)bz * Kd;
+    // split-K: block z of gridDim.z owns the k-slabs [z n / Z, (z + 1) n / Z) of the n = Kd / KS (the split need not
+    // divide them) and writes its partial product to slab z
+    const int s_lo = (int)((long)bz * (Kd / KS) / gridDim.z), s_hi = (int)((long)(bz + 1) * (Kd / KS) / gridDim.z);
+    L += (long)s_lo * KS;
+    R += (long)s_lo * KS;
     C += (long)bz * slab;
     constexpr int NWN = BN / WN;
     constexpr int NTHR = (BM / WM) * NWN * 64;
@@ -96,7 +98,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64) void k_gemm_nt(
     for (int e = 0; e < ER; ++e) sR[0][rk + e][rrow] = vr[e];
     __syncthreads();
 
-    const int nslab = Kd / KS;
+    const int nslab = s_hi - s_lo;
     for (int sl = 0; sl < nslab; ++sl) {
         const int buf = sl & 1;
         const bool more = sl + 1 < nslab;
@@ -196,7 +198,7 @@ static hipError_t launch_nt(const T* L, int ldl, const T* R, int ldr, T* C, int 
                             int Kd, const MuEpilogue<T>& ep, hipStream_t s, int splits = 1, long slab = 0, int jv = 0) {
     dim3 grid(J / BN, I / BM, splits), block((BM / WM) * (BN / WN) * 64);
     hipLaunchKernelGGL((k_gemm_nt<T, BM, BN, WM, WN, MU>), grid, block, 0, s, L, ldl, R, ldr, C, ldc,
-                       Kd / splits, ep, slab, jv > 0 ? jv : J);
+                       Kd, ep, slab, jv > 0 ? jv : J);
     return hipGetLastError();
 }
 
@@ -254,11 +256,29 @@ hipError_t gemm_nt(const T* L, int ldl, const T* R, int ldr, T* C, int ldc, int 
         int splits = 1;
         const long slab = (long)I * ldc;
         if (scratch && ldc == J) {
-            // the largest split (<= 8) that divides the k-slabs evenly, keeps <= 1024 workgroups and leaves every
-            // workgroup a worthwhile chunk (512 deep for long contractions, 64 for short ones such as the
-            // 400-point DFTs of Griffin-Lim, whose 84 tiles would otherwise run 25 slabs each on a third of the CUs)
+            // The split (<= 8, not necessarily a divisor of the k-slabs) that is expected to finish first: a CU works
+            // on up to four of these workgroups at once, one wavefront of each per SIMD, so a launch lasts about
+            // (most workgroups on one CU) x (one workgroup's work ~ 1 / split), a little longer when few workgroups
+            // share a CU (their latencies are less well covered: 0.6 / 0.8 / 0.9 / 0.95 of the matrix rate for 1..4).
+            // C3's V = H Am^T (99 tiles): 7 ranges put at most 3 workgroups on a CU where 8 put 4 on some.  Every
+            // workgroup keeps a worthwhile chunk (512 deep for long contractions, 64 for short ones such as the
+            // 400-point DFTs of Griffin-Lim, whose 84 tiles would otherwise run 25 slabs each on a third of the CUs).
+            int dev = 0, cus = 0;
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+                cus = 256;
+            static const double eff[5] = {1.0, 0.6, 0.8, 0.9, 0.95};
             const int nslabs = Kd / KS, chunk = Kd >= 1024 ? 512 : 64;
-            for (int sp = 2; sp <= 8; ++sp)
+            double best = 1e30;
+            for (int sp = 1; sp <= 8 && Kd >= 1024; ++sp) {
+                if (blocks * sp > 4L * cus || (sp > 1 && (nslabs / sp) * KS < chunk) || (size_t)sp * slab > scratch_elems) continue;
+                const long per_cu = (blocks * sp + cus - 1) / cus;
+                const double cost = (double)per_cu / sp / eff[per_cu];
+                if (cost < best - 1e-9) { best = cost; splits = sp; }
+            }
+            // short contractions (measured on Griffin-Lim's: 12.7 ms per 300 iterations with the rule above against
+            // 11.2): the largest split that divides the k-slabs evenly
+            for (int sp = 2; sp <= 8 && Kd < 1024; ++sp)
                 if (nslabs % sp == 0 && blocks * sp <= 1024 && Kd / sp >= chunk && (size_t)sp * slab <= scratch_elems)
                     splits = sp;
         }
