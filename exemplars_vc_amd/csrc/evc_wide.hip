@@ -222,8 +222,40 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
         const bool kl = a.mode == WIDE_KL;
         if (nb > 0) stage_block(j0, 0);       // (the dictionary does not depend on anybody: its first block is on its way
                                               // while the group's counter is polled)
+        // Is any frame of this group live (its utterance has not stopped)?  The same answer in every wavefront, without
+        // a barrier; the flags do not change during a launch and the loads run beside the dependency wait.
+        bool grp_live = false;
+        if (it > 0) {
+#pragma unroll
+            for (int k = 0; k < (W * 16 + 63) / 64; ++k) {
+                const int t = (g * W) * 16 + k * 64 + lane;
+                if (k * 64 + lane < W * 16 && t < a.T_) {
+                    const int ut = a.frame_utt[t];
+                    if (ut >= 0 && a.active[ut] != 0) grp_live = true;
+                }
+            }
+            grp_live = __ballot(grp_live ? 1 : 0) != 0;
+        }
         if (it > 0 && !wait_for(a.rmode ? a.done_r + g : a.done + g, c * (unsigned)it)) break;
         WSTAMP(1);
+        if (it > 0 && !grp_live) {
+            // A frame group whose utterances have all stopped (or that is padding) does not sweep: its H stays, and so
+            // does V' = A H - the task republishes the partial it published one iteration ago (the same bits).
+            if (on) {
+                const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.Vpart + ((((size_t)((par ^ 1u) * a.G + g) * c + e) * W + w)) * (TILE_B / 4), TILE_B);
+                const __amdgpu_buffer_rsrc_t rdst = make_rsrc(a.Vpart + ((((size_t)(par * a.G + g) * c + e) * W + w)) * (TILE_B / 4), TILE_B);
+#pragma unroll
+                for (int u = 0; u < MT; ++u) st_sc1(rdst, (u * 64 + lane) * 16u, ld_sc1(rsrc, (u * 64 + lane) * 16u));
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the staged block of this task too)
+            __syncthreads();
+            if (tid == 0) {
+                __hip_atomic_fetch_add(a.done + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_ctl[0] = nxt;
+            }
+            __syncthreads();
+            continue;
+        }
 
         f32x4 Vin[MT], Vn[MT];
 #pragma unroll
@@ -231,25 +263,6 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
         bool live = false;
         float h0v = 0.f;
         if (on) {
-            const int t = ft * 16 + i16;
-            if (t < a.T_) {
-                const int ut = a.frame_utt[t];
-                if (ut >= 0) {
-                    live = a.active[ut] != 0;
-                    h0v = (float)a.h0[ut];
-                }
-            }
-        }
-        // A frame group whose utterances have all stopped (or that is padding) does not sweep: its H stays, and so does
-        // V' = A H - the task republishes the partial it published one iteration ago (the same bits a sweep would give).
-        const bool idle = it > 0 && !__syncthreads_or(live ? 1 : 0);
-        if (on && idle) {
-            const __amdgpu_buffer_rsrc_t rv =
-                make_rsrc(a.Vpart + ((((size_t)((par ^ 1u) * a.G + g) * c + e) * W + w)) * (TILE_B / 4), TILE_B);
-#pragma unroll
-            for (int u = 0; u < MT; ++u) Vn[u] = ld_sc1(rv, (u * 64 + lane) * 16u);
-        }
-        if (on && !idle) {
             const f32x4* xt = reinterpret_cast<const f32x4*>(a.Xw) + (size_t)ft * (MT * 64) + lane;
             if (it == 0) {
 #pragma unroll
@@ -278,6 +291,14 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
                     for (int r = 0; r < 4; ++r) Vin[u][r] = x[r] / (Vin[u][r] < a.eps ? a.eps : Vin[u][r]);
                 }
             }
+            const int t = ft * 16 + i16;
+            if (t < a.T_) {
+                const int ut = a.frame_utt[t];
+                if (ut >= 0) {
+                    live = a.active[ut] != 0;
+                    h0v = (float)a.h0[ut];
+                }
+            }
         }
         const __amdgpu_buffer_rsrc_t rh = make_rsrc(a.Hw + (size_t)(on ? ft : 0) * a.NB * 256, (unsigned)a.NB * 1024u);
         const __amdgpu_buffer_rsrc_t rp = make_rsrc(a.Pw + (size_t)(on ? ft : 0) * a.NB * 256, (unsigned)a.NB * 1024u);
@@ -286,7 +307,7 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
         const float c0 = it == 0 ? 0.f : a.l1 + (a.mode == EVC_EPS_ADD ? a.eps : 0.f);
         const int n_edge = (a.N & 15) ? a.NB - 1 : -1;           // the block that reaches into the zero padding
         f32x4 hC = f32x4{0, 0, 0, 0}, pC = hC, hN = hC, pN = hC;
-        if (on && nb > 0 && !idle) {
+        if (on && nb > 0) {
             if (load_h) hC = ld_sc1(rh, (j0 * 64 + lane) * 16u);
             if (load_p) pC = ld_sc1(rp, (j0 * 64 + lane) * 16u);
         }
@@ -425,7 +446,7 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
         const char* s2P = nullptr;         // ... and that block's V' image
         bool qa2 = false;                  // q0 / q1 hold the first fragment pair of that image
         int st = 0;                        // LDS stage of block i
-        for (int i = 0; i < (idle ? 0 : nb); ++i) {
+        for (int i = 0; i < nb; ++i) {
             const int jb = j0 + i, stn = st == NSTAGE - 1 ? 0 : st + 1;
             const char* sb = smem + (no_dma ? 0 : st) * IMG;
             const char* s2 = sb + MT * 1024;
