@@ -25,8 +25,8 @@
 //   the four quarters of H' meet in LDS again (4 KiB).  Two LDS-only barriers per block, no global drain.
 // * The dictionary goes global -> LDS -> registers with nothing to share: the A-operand fragments of a wavefront's own
 //   bins are private to it (its three neighbours hold other bins).  A wavefront's fragments are stored in the order
-//   it consumes them (Aw[w][chunk b] = D image of block b, then V' image of block b - 1), so its stream is one linear
-//   walk; it runs through a private ring of 32 KiB-slots filled by LDS-DMA (global_load_lds_dwordx4, no registers,
+//   it consumes them (Aw[w][chunk b] = D image of block b, the split tile's position, V' image of block b - 1), so its
+//   stream is one linear walk; it runs through a private ring of 32 slots of 1 KiB filled by LDS-DMA (global_load_lds_dwordx4, no registers,
 //   32 KiB in flight per wavefront - 32 frames per CU means the whole 75 MB image passes every CU once per
 //   iteration, ~16 B/clk/CU at the matrix rate, and latency x bandwidth needs that much in flight); one 16-byte
 //   ds_read per lane feeds two k-steps x two frame tiles = four 64-cycle MFMAs.
