@@ -277,7 +277,8 @@ def main():
     ap.add_argument("--loss", default="frobenius", choices=["frobenius", "kl"],
                     help="kl: the KL update of _factorize's signature default (not the headline metric)")
     ap.add_argument("--no-fused", action="store_true")
-    ap.add_argument("--no-all-resident", action="store_true", help="A/B: keep k_fused_all out")
+    ap.add_argument("--no-all-resident", action="store_true", help="A/B: keep k_fused_all / k_fused_xy out")
+    ap.add_argument("--no-pair-tiles", action="store_true", help="A/B: k_fused_all (round 2) instead of k_fused_xy")
     ap.add_argument("--fused-c", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-transfer-inclusive leg")
@@ -356,7 +357,7 @@ def main():
     counts = {"redo": 0}
     solve_kw = dict(layout="frame_major", iters=K, eps_mode="zero_replace", init="sklearn", algo=args.algo, l1=l1,
                     fused=not args.no_fused, fused_c=args.fused_c, loss=args.loss,
-                    all_resident=not args.no_all_resident)
+                    all_resident=not args.no_all_resident, pair_tiles=not args.no_pair_tiles)
 
     def step(timed):
         # factorize() + convert(): H (T x N) and Y = H B (T x Mb) both delivered in HBM
@@ -393,11 +394,12 @@ def main():
         achieved = fl_loop / loop_s / 1e12
         # the kernel the library reports it ran (evc_solve_info), not a guess from the shape
         ktag = sinfo.get("kernel", "unknown")
-        fused64 = ktag in ("k_fused_all", "k_fused_res", "k_fused_mu")
+        fused64 = ktag in ("k_fused_xy", "k_fused_all", "k_fused_res", "k_fused_mu")
         # float32 callers with M <= 32 are widened onto the float64 fused kernels: the arithmetic type is f64
         arith = "f64" if (dtype == "f64" or fused64) else "f32"
         peak = PEAK_F64_TFLOPS if arith == "f64" else PEAK_F32_TFLOPS
         kernel = {
+            "k_fused_xy": "k_fused_xy (persistent: H and P register-resident, a member = 256 exemplars of TWO frame tiles, exchange phases of one tile inside the sweep of the other, two free-running members per CU)",
             "k_fused_all": "k_fused_all (persistent: H and P register-resident, two members per CU alternating sweep / exchange)",
             "k_fused_res": "k_fused_res (persistent, half of H register-resident, P recomputed)",
             "k_fused_mu": "k_fused_mu (persistent fused update, activations streamed)",

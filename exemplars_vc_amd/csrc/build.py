@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 OBJ = os.path.join(HERE, "_build")
 LIB = os.path.join(PKG, "libevc_hip.so")
-SOURCES = ["evc_gemm.hip", "evc_gemm2.hip", "evc_aux.hip", "evc_fused.hip", "evc_fused_res.hip", "evc_fused_all.hip", "evc_wide.hip", "evc_wide64.hip", "evc_gl.hip", "evc_dtw.hip", "evc_api.hip"]
+SOURCES = ["evc_gemm.hip", "evc_gemm2.hip", "evc_aux.hip", "evc_fused.hip", "evc_fused_res.hip", "evc_fused_all.hip", "evc_fused_xy.hip", "evc_wide.hip", "evc_wide64.hip", "evc_gl.hip", "evc_dtw.hip", "evc_api.hip"]
 HEADERS = ["evc_internal.h", "evc_fused_common.h", os.path.join("..", "..", "include", "evc.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 EXTRA_FLAGS = {}

@@ -255,7 +255,7 @@ int prepare_dict_fused(const DictArrays<double>& a, const DictPlan& p, const dou
             HIP_TRY(fused_pack_dict(fl, a.A1p, nullptr, a.Akl, d.Mk, d.Np, s));
             HIP_TRY(fused_pack_dict(fl, nullptr, a.A2p, a.At, d.Mk, d.Np, s));
         } else {
-            HIP_TRY(fused_pack_dict(fl, a.A1p, a.A2p, a.At, d.Mk, d.Np, s));
+            HIP_TRY(fused_pack_dict(fl, a.A1p, a.A2p, a.At, d.Mk, d.Np, s, (d.M % 4) ? d.M : -1));
         }
         if (want_rowsum) HIP_TRY(fused_rowsum(a.At, d.Mk, d.M, d.N, a.rsum, s));
     }
@@ -350,6 +350,7 @@ int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_sol
     FusedBuffers fb = w.fb;
     fb.coop_c = 1;
     fb.all_c = 0;
+    fb.xy_c = 0;
     int dev = 0, cus = 0;
     HIP_TRY(hipGetDevice(&dev));
     HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -359,25 +360,29 @@ int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_sol
     if (c_override == 0 && !(o.reserved & 16)) {
         const int c = fused_all_members(w.fl.NT, d.N, o.eps_mode, exact_div, o.loss);
         if (c == 1 || (c > 1 && c <= cus && !(o.reserved & 4))) fb.all_c = c;
+        // two frame tiles per member, exchange inside the sweeps (k_fused_xy): every shape with an exchange;
+        // reserved bit 5 keeps k_fused_all (A/B timing)
+        const int cx = fused_xy_members(w.fl.NT, d.N, o.eps_mode, exact_div, o.loss);
+        if (cx >= 2 && cx <= 2 * cus && !(o.reserved & 4) && !(o.reserved & 32)) { fb.xy_c = cx; fb.all_c = 0; }
     }
-    if (!fb.all_c && !(o.reserved & 4) && c_override == 0 && fused_res_supported(d.N, o.eps_mode, exact_div))
+    if (!fb.all_c && !fb.xy_c && !(o.reserved & 4) && c_override == 0 && fused_res_supported(d.N, o.eps_mode, exact_div))
         fb.coop_c = fused_res_coop_factor(w.fl.NT, w.fl.TT, cus);
     // start values: caller-given ones were imported by the caller of this function; constants are either written
     // into the packed tiles here, or - first launch on k_fused_all, no residual wanted at init - formed by that kernel
     fb.init_const = 0;
     if (o.init_mode != EVC_INIT_GIVEN) {
-        if (fb.all_c >= 1 && o.iters > 0 && !(o.check_every > 0 && o.stop_rule == EVC_STOP_SKLEARN)) {
+        if ((fb.all_c >= 1 || fb.xy_c >= 2) && o.iters > 0 && !(o.check_every > 0 && o.stop_rule == EVC_STOP_SKLEARN)) {
             if (!o.dict) HIP_TRY(fused_rowsum(w.At, d.Mk, d.M, d.N, fb.rsum, s));
             fb.init_const = 1;
         } else {
             HIP_TRY(fused_fill_h(w.fl, fb.Hp, d.N, d.T_, w.u, s));
         }
     }
-    const bool exchanges = fb.coop_c > 1 || fb.all_c > 1;
-    inf->kernel = fb.all_c >= 1 ? EVC_KERNEL_FUSED_ALL
+    const bool exchanges = fb.coop_c > 1 || fb.all_c > 1 || fb.xy_c > 1;
+    inf->kernel = fb.xy_c >= 2 ? EVC_KERNEL_FUSED_XY : fb.all_c >= 1 ? EVC_KERNEL_FUSED_ALL
                   : ((c_override == 0 && fused_res_supported(d.N, o.eps_mode, exact_div)) ? EVC_KERNEL_FUSED_RES
                                                                                           : EVC_KERNEL_FUSED_MU);
-    inf->members = fb.all_c >= 1 ? fb.all_c : fb.coop_c;
+    inf->members = fb.xy_c >= 2 ? fb.xy_c : fb.all_c >= 1 ? fb.all_c : fb.coop_c;
     inf->exchange = exchanges ? 1 : 0;
     int* coop_abort = fb.coop_cnt + COOP_MAX_TILES;
     // tests only (evc_solve_opts.test_abort_at, 0 in production): k > 0 raises the abort flag in front of the k-th
@@ -399,7 +404,7 @@ int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_sol
         bool check = false;
         if (o.check_every > 0 && n >= o.check_every) { n = o.check_every; check = true; }
         // the last launch of a solve in which nothing can stop writes the caller's H itself (k_fused_all)
-        if (H_out && fb.all_c >= 1 && c_override == 0 && o.stop_rule == EVC_STOP_NONE && done + n == o.iters) {
+        if (H_out && (fb.all_c >= 1 || fb.xy_c >= 2) && c_override == 0 && o.stop_rule == EVC_STOP_NONE && done + n == o.iters) {
             fb.Hx = H_out; fb.ldhx = ldh; fb.hx_frame_major = o.layout == EVC_FRAME_MAJOR ? 1 : 0;
             *exported = 1;
         }

@@ -37,7 +37,7 @@ namespace evc {
 // At has n_rows rows (zero beyond the true N); exemplar slots from n_rows on - the tile count may be padded past
 // the array, see fused_layout - are written as zeros, never read.
 __global__ void k_pack_dict(const double* __restrict__ At, int ldA, int n_rows, int NT, int msteps, int mtiles,
-                            double* __restrict__ A1p, double* __restrict__ A2p) {
+                            double* __restrict__ A1p, double* __restrict__ A2p, int ones_bin) {
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int msp = (msteps + 1) & ~1;
     const long n1 = (long)NT * msp * 64, n2 = (long)NT * mtiles * 4 * 64;
@@ -46,7 +46,8 @@ __global__ void k_pack_dict(const double* __restrict__ At, int ldA, int n_rows, 
         const long j = (gid >> 7) / (msp / 2);
         const int i = l & 15;
         const long n = 16 * j + 4 * (i & 3) + (i >> 2);
-        if (A1p) A1p[gid] = (s < msteps && n < n_rows) ? At[n * ldA + bin_of(s, l >> 4)] : 0.0;
+        const int bin = bin_of(s, l >> 4);
+        if (A1p) A1p[gid] = (s < msteps && bin == ones_bin) ? 1.0 : ((s < msteps && n < n_rows) ? At[n * ldA + bin] : 0.0);
     } else if (gid < n1 + n2) {
         const long g = gid - n1;
         const int e = g & 1, l = (g >> 1) & 63, r = 2 * (int)((g >> 7) & 1) + e, u = (g >> 8) % mtiles;
@@ -391,6 +392,7 @@ FusedLayout fused_layout(int M, int N, int T_) {
     FusedLayout f;
     f.msteps = fused_msteps(M);
     f.mtiles = M > 16 ? 2 : 1;
+    f.M = M;
     // from 1024 exemplars on (k_fused_res: 8 wavefronts x >= 8 tiles) the tile count is padded to whole
     // rounds of the 8 wavefronts; padding exemplars have zero dictionary columns and zero activations, and
     // 0 * 0 / guard keeps them at zero under every guarded eps mode
@@ -410,10 +412,10 @@ FusedLayout fused_layout(int M, int N, int T_) {
 }
 
 hipError_t fused_pack_dict(const FusedLayout& f, double* A1p, double* A2p, const double* At, int ldA, int n_rows,
-                           hipStream_t s) {
+                           hipStream_t s, int ones_bin) {
     const long n = (long)f.a1 + (long)f.a2;
     hipLaunchKernelGGL(k_pack_dict, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, At, ldA, n_rows, f.NT, f.msteps,
-                       f.mtiles, A1p, A2p);
+                       f.mtiles, A1p, A2p, ones_bin);
     return hipGetLastError();
 }
 
@@ -521,8 +523,11 @@ hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttS
     a.eps_mode = eps_mode; a.eps = eps; a.l1 = l1;
     a.coop_c = 1; a.coop_buf = nullptr; a.coop_cnt = nullptr; a.coop_abort = nullptr; a.groups = 0;
     a.init_const = 0; a.h0 = nullptr; a.rsum = nullptr; a.Hx = nullptr; a.ldhx = 0; a.hx_frame_major = 0;
-    const bool all_res = c_req == 0 && b.all_c >= 1 && b.coop_buf && b.coop_cnt &&
-                         fused_all_members(f.NT, N, eps_mode, exact_div, loss) == b.all_c;
+    a.M = f.M; a.spare_q = -1;
+    const bool xy = c_req == 0 && b.xy_c >= 2 && b.coop_buf && b.coop_cnt &&
+                    fused_xy_members(f.NT, N, eps_mode, exact_div, loss) == b.xy_c;
+    const bool all_res = xy || (c_req == 0 && b.all_c >= 1 && b.coop_buf && b.coop_cnt &&
+                                fused_all_members(f.NT, N, eps_mode, exact_div, loss) == b.all_c);
     const bool resident = all_res || (c_req == 0 && fused_res_supported(N, eps_mode, exact_div));
     if (!resident) return launch_general(f, a, c_req, s);
     if (first && all_res && b.init_const && iters > 0) {
@@ -539,10 +544,10 @@ hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttS
     if (iters == 0) return hipSuccess;
     hipError_t e;
     if (all_res) {
-        a.coop_c = b.all_c; a.coop_buf = b.coop_buf; a.coop_cnt = b.coop_cnt;
+        a.coop_c = xy ? b.xy_c : b.all_c; a.coop_buf = b.coop_buf; a.coop_cnt = b.coop_cnt;
         a.coop_abort = b.coop_cnt + COOP_MAX_TILES;
         if (all_live_known) { a.Hx = b.Hx; a.ldhx = b.ldhx; a.hx_frame_major = b.hx_frame_major; }
-        e = fused_all_launch(f.msteps, a, b.n_cus, s);
+        e = xy ? fused_xy_launch(f.msteps, a, b.n_cus, s) : fused_all_launch(f.msteps, a, b.n_cus, s);
         a.coop_c = 1;            // the general kernel behind it takes no part in any exchange
         a.first = 0; a.init_const = 0; a.Hx = nullptr;
     } else {
@@ -569,7 +574,7 @@ hipError_t fused_synthesize(const FusedLayout& fB, const double* B2p, const doub
     a.NT = fB.NT; a.TT = fB.TT; a.N = N; a.T_ = T_;
     a.iters = 0; a.first = 1; a.write_err = 0; a.skip_all_live = 0; a.force_live = 1; a.loss = EVC_LOSS_FROBENIUS; a.exact_div = 0;
     a.Hx = nullptr; a.ldhx = 0; a.hx_frame_major = 0;
-    a.init_const = 0; a.h0 = nullptr; a.rsum = nullptr;
+    a.init_const = 0; a.h0 = nullptr; a.rsum = nullptr; a.M = fB.M; a.spare_q = -1;
     a.coop_c = 1; a.coop_buf = nullptr; a.coop_cnt = nullptr; a.coop_abort = nullptr; a.groups = 0;
     a.eps_mode = EVC_EPS_ADD; a.eps = 0; a.l1 = 0;
     hipError_t e = dispatch_msteps<1>(fB.msteps, a, s);

@@ -53,7 +53,10 @@ struct FusedArgs {
     double* Hx;              // NULL: off
     long ldhx;
     int hx_frame_major;      // 1: Hx[t * ldhx + n], 0: Hx[n * ldhx + t]
-#ifdef EVC_ALL_TIMING
+    // k_fused_xy: bins of the dictionary (0: unknown) and the lane group of the last k-step that holds the spare bin M
+    // in which the denominators' start value travels (-1: not used); see evc_fused_xy.hip
+    int M, spare_q;
+#if defined(EVC_ALL_TIMING) || defined(EVC_XY_TIMING)
     long long* dbg;          // tools/ubench/fused_all_bench.hip: s_memtime stamps of the first round's steps
 #endif
 };
@@ -261,6 +264,8 @@ __device__ __forceinline__ void mu_quot_exact(const f64x4& p, const f64x4& dacc,
 hipError_t fused_res_launch(int msteps, const FusedArgs& a, hipStream_t s);
 // evc_fused_all.hip: every activation and numerator tile register-resident, NT / 32 workgroups per frame tile
 hipError_t fused_all_launch(int msteps, const FusedArgs& a, int n_cus, hipStream_t s);
+// evc_fused_xy.hip: the same with two frame tiles per member and the exchange inside the sweeps, NT / 16 workgroups per pair
+hipError_t fused_xy_launch(int msteps, const FusedArgs& a, int n_cus, hipStream_t s);
 
 // per-frame share of 2 KL(X || A H) from the B-operand images of X and V held by one lane
 // (sklearn _nmf.py:136-160: log term only where x > eps, V floored at eps there, plus sum(V))

@@ -161,6 +161,7 @@ struct FusedLayout {
     int TT, TTp;         // frame tiles of 16 (TTp: padded to a multiple of 4)
     int msteps;          // k-steps of 4 bins actually issued
     int mtiles;          // 1 (M <= 16) or 2
+    int M;               // bins
     size_t a1, a2, xp, hp, vp;   // element counts of the packed arrays
 };
 constexpr int COOP_MAX_TILES = 256;       // frame tiles x cooperating workgroups never exceeds this (one per CU)
@@ -173,6 +174,8 @@ constexpr long ALL_SLICE_ELEMS = 2L * (ALL_MAX_WGS / 2) * 512;    // [2][groups 
 int fused_res_coop_factor(int NT, int TT, int n_cus);
 // workgroups per frame tile the all-resident kernel (k_fused_all) uses for this problem; 0: it does not apply
 int fused_all_members(int NT, int N, int eps_mode, int exact_div, int loss);
+// workgroups per PAIR of frame tiles k_fused_xy (evc_fused_xy.hip) uses for this problem; 0: it does not apply
+int fused_xy_members(int NT, int N, int eps_mode, int exact_div, int loss);
 bool fused_res_supported(int N, int eps_mode, int exact_div);
 struct FusedBuffers {
     double *A1p, *A2p, *Xp, *Hp, *Vp;
@@ -180,6 +183,7 @@ struct FusedBuffers {
     int* coop_cnt;         // [COOP_MAX_TILES] arrival counters, then one abort flag
     int coop_c;            // cooperating workgroups per frame tile chosen for this call (1 = off)
     int all_c;             // k_fused_all: workgroups per frame tile (0 = that kernel is not used)
+    int xy_c;              // k_fused_xy: workgroups per pair of frame tiles (0 = that kernel is not used)
     double* rsum;          // [32] row sums of the dictionary (k_fused_all's in-kernel start)
     int init_const;        // 1: the first launch forms H = h0 and V = h0 rowsum(A) itself (no fill, no pre-pass)
     double* Hx;            // k_fused_all's last launch also writes the caller's H (NULL: off); ldhx, hx_frame_major
@@ -192,8 +196,11 @@ FusedLayout fused_layout(int M, int N, int T_);
 // At[n][m] / Xt[t][m]: the zero-padded frames-as-rows workspace arrays
 // (either destination may be NULL: only the other fragment order is written); At has n_rows rows: the exemplar
 // slots of the (possibly further padded) tile grid beyond them are written as zeros
+// ones_bin >= 0: that (padding) bin of the D-operand image holds 1.0 in every exemplar slot, so that a constant placed in
+// the same bin of V's image is added to every denominator by the D product itself (k_fused_xy; the images of X and V
+// hold zeros there otherwise, so every other kernel is unaffected)
 hipError_t fused_pack_dict(const FusedLayout& f, double* A1p, double* A2p, const double* At, int ldA, int n_rows,
-                           hipStream_t s);
+                           hipStream_t s, int ones_bin = -1);
 hipError_t fused_pack_frames(const FusedLayout& f, double* Xp, const double* Xt, int ldx, hipStream_t s);
 // rsum[m] = sum_n At[n][m] for m < M (fixed order), 0 for M <= m < 32
 hipError_t fused_rowsum(const double* At, int ldA, int M, int N, double* rsum, hipStream_t s);

@@ -163,7 +163,9 @@ enum {
     EVC_KERNEL_FUSED_RES = 4,   /* k_fused_res: half of H register-resident (members > 1: its cooperative launch) */
     EVC_KERNEL_FUSED_ALL = 5,   /* k_fused_all: H and P register-resident, `members` workgroups per frame tile */
     EVC_KERNEL_FUSED_WIDE = 6,  /* k_fused_wide: fused FACTORED for float32, 32 < M <= 208: task queue over (frame group, exemplar range) */
-    EVC_KERNEL_FUSED_WIDE64 = 7 /* k_fused_wide64: the same for float64, 208 < M <= 528 (bins split over a workgroup's wavefronts) */
+    EVC_KERNEL_FUSED_WIDE64 = 7, /* k_fused_wide64: the same for float64, 208 < M <= 528 (bins split over a workgroup's wavefronts) */
+    EVC_KERNEL_FUSED_XY = 8     /* k_fused_xy: H and P register-resident, `members` workgroups per PAIR of frame tiles, the
+                                   exchange inside the sweeps (round 4; serves every M <= 32 shape with more than 256 exemplars) */
 };
 
 typedef struct evc_solve_info {
