@@ -278,7 +278,7 @@ def main():
                     help="kl: the KL update of _factorize's signature default (not the headline metric)")
     ap.add_argument("--no-fused", action="store_true")
     ap.add_argument("--no-all-resident", action="store_true", help="A/B: keep k_fused_all / k_fused_xy out")
-    ap.add_argument("--no-pair-tiles", action="store_true", help="A/B: k_fused_all (round 2) instead of k_fused_xy")
+    ap.add_argument("--pair-tiles", action="store_true", help="A/B: the experimental k_fused_xy instead of k_fused_all")
     ap.add_argument("--fused-c", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-transfer-inclusive leg")
@@ -357,7 +357,7 @@ def main():
     counts = {"redo": 0}
     solve_kw = dict(layout="frame_major", iters=K, eps_mode="zero_replace", init="sklearn", algo=args.algo, l1=l1,
                     fused=not args.no_fused, fused_c=args.fused_c, loss=args.loss,
-                    all_resident=not args.no_all_resident, pair_tiles=not args.no_pair_tiles)
+                    all_resident=not args.no_all_resident, pair_tiles=args.pair_tiles)
 
     def step(timed):
         # factorize() + convert(): H (T x N) and Y = H B (T x Mb) both delivered in HBM

@@ -19,7 +19,7 @@ ALGO_GRAM, ALGO_FACTORED, ALGO_LITERAL, ALGO_AUTO = 0, 1, 2, 3
 INIT_GIVEN, INIT_SKLEARN, INIT_CONST = 0, 1, 2
 STOP_NONE, STOP_SKLEARN, STOP_PYMF = 0, 1, 2
 LOSS_FROBENIUS, LOSS_KL = 0, 1
-FLAG_NO_FUSED, FLAG_EXACT_DIV, FLAG_NO_EXCHANGE, FLAG_NO_ALL_RESIDENT, FLAG_NO_XY = 1, 2, 4, 16, 32
+FLAG_NO_FUSED, FLAG_EXACT_DIV, FLAG_NO_EXCHANGE, FLAG_NO_ALL_RESIDENT, FLAG_PAIR_TILES = 1, 2, 4, 16, 32
 
 # every symbol include/evc.h declares; tests check that the library exports all of them
 SYMBOLS = ("evc_version", "evc_strerror", "evc_device_count", "evc_workspace_bytes",

@@ -360,10 +360,10 @@ int solve_fused<double>(const Workspace<double>& w, const Dims& d, const evc_sol
     if (c_override == 0 && !(o.reserved & 16)) {
         const int c = fused_all_members(w.fl.NT, d.N, o.eps_mode, exact_div, o.loss);
         if (c == 1 || (c > 1 && c <= cus && !(o.reserved & 4))) fb.all_c = c;
-        // two frame tiles per member, exchange inside the sweeps (k_fused_xy): every shape with an exchange;
-        // reserved bit 5 keeps k_fused_all (A/B timing)
+        // two frame tiles per member, exchange inside the sweeps (k_fused_xy, round 4): measured slower than k_fused_all
+        // (profiles/r04_xy_notes.md), so only on request - reserved bit 5, EVC_FLAG_PAIR_TILES
         const int cx = fused_xy_members(w.fl.NT, d.N, o.eps_mode, exact_div, o.loss);
-        if (cx >= 2 && cx <= 2 * cus && !(o.reserved & 4) && !(o.reserved & 32)) { fb.xy_c = cx; fb.all_c = 0; }
+        if (cx >= 2 && cx <= 2 * cus && !(o.reserved & 4) && (o.reserved & 32)) { fb.xy_c = cx; fb.all_c = 0; }
     }
     if (!fb.all_c && !fb.xy_c && !(o.reserved & 4) && c_override == 0 && fused_res_supported(d.N, o.eps_mode, exact_div))
         fb.coop_c = fused_res_coop_factor(w.fl.NT, w.fl.TT, cus);

@@ -274,7 +274,9 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
                         if (u * 4 + r < MSTEPS) red[w * E + (u * 4 + r) * 64 + lane] = vn[u][r];
             } else if (valid && !mine && step > 0) {
                 // ---------------- exchange: V' = sum over wavefronts and members, no barrier inside
-                const int e0 = th, e1 = th + AW * 64;
+                // (run-time member counts with M <= 12: fewer elements than threads - several threads carry one element, word
+                // for word; a thread beyond NE used to poll a word of the summed slices that nobody writes)
+                const int e0 = C <= 0 ? th % NE : th, e1 = th + AW * 64;
                 const bool has1 = e1 < NE;
                 double s0 = 0.0, s1 = 0.0;
 #pragma unroll

@@ -240,7 +240,7 @@ def _solve(A, X, H0, B, *, layout="bin_major", iters=100, eps_mode="add", eps=No
            stop_rule="none", tol=0.0, utt_offsets: Optional[Sequence[int]] = None,
            dtype=None, device=None, info=False, out=None, loop_events=None,
            fused=True, fused_c=0, fused_w=0, want_h=True, out_y=None, loss="frobenius", exact_div=False,
-           cooperative=True, all_resident=True, pair_tiles=True, _fake_coop_timeout=False, solve_info=None):
+           cooperative=True, all_resident=True, pair_tiles=False, _fake_coop_timeout=False, solve_info=None):
     torch = _torch()
     device = require_device(device)
     L = _lib.lib()
@@ -320,13 +320,13 @@ def _solve(A, X, H0, B, *, layout="bin_major", iters=100, eps_mode="add", eps=No
     opts.l1, opts.tol, opts.init_value = float(l1), float(tol), float(init_value)
     opts.loss = _LOSSES[loss]
     # EVC_FLAG_* of include/evc.h: NO_FUSED, EXACT_DIV, NO_EXCHANGE (cooperative=False: no kernel in which
-    # workgroups exchange data inside a launch - the call is then fully asynchronous), NO_ALL_RESIDENT, NO_XY
-    # (pair_tiles=False: k_fused_all instead of k_fused_xy, A/B timing); bits
+    # workgroups exchange data inside a launch - the call is then fully asynchronous), NO_ALL_RESIDENT, PAIR_TILES
+    # (pair_tiles=True: the experimental k_fused_xy instead of k_fused_all); bits
     # 8..15 = 1 or 2 force the general streamed kernel with that many frame tiles per workgroup (tuning; on the wide
     # float32 path: exemplar ranges per frame group), bits 16..19 = wavefronts per workgroup of k_fused_wide (4 / 8)
     opts.reserved = ((0 if fused else _lib.FLAG_NO_FUSED) | (_lib.FLAG_EXACT_DIV if exact_div else 0)
                      | (0 if cooperative else _lib.FLAG_NO_EXCHANGE)
-                     | (0 if all_resident else _lib.FLAG_NO_ALL_RESIDENT) | (0 if pair_tiles else _lib.FLAG_NO_XY)
+                     | (0 if all_resident else _lib.FLAG_NO_ALL_RESIDENT) | (_lib.FLAG_PAIR_TILES if pair_tiles else 0)
                      | ((int(fused_c) & 0xff) << 8)
                      | ((int(fused_w) & 0xf) << 16))
     if _fake_coop_timeout is not False and _fake_coop_timeout is not None:

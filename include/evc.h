@@ -109,8 +109,10 @@ enum { EVC_LOSS_FROBENIUS = 0, EVC_LOSS_KL = 1 };
  *                    else a shared / refined reciprocal, <= 2 ulp)
  *   NO_EXCHANGE      no kernel in which workgroups exchange data inside a launch: the call is then fully
  *                    asynchronous (see "Host synchronisation" above); a latency / determinism knob
- *   NO_ALL_RESIDENT  keep k_fused_all out (k_fused_res, with its cooperative launch for few frame tiles) */
-enum { EVC_FLAG_NO_FUSED = 1, EVC_FLAG_EXACT_DIV = 2, EVC_FLAG_NO_EXCHANGE = 4, EVC_FLAG_NO_ALL_RESIDENT = 16 };
+ *   NO_ALL_RESIDENT  keep k_fused_all out (k_fused_res, with its cooperative launch for few frame tiles)
+ *   PAIR_TILES       tuning / experiments: k_fused_xy (two frame tiles per member, exchange phases inside the sweeps)
+ *                    instead of k_fused_all where both apply; measured slower (profiles/r04_xy_notes.md) */
+enum { EVC_FLAG_NO_FUSED = 1, EVC_FLAG_EXACT_DIV = 2, EVC_FLAG_NO_EXCHANGE = 4, EVC_FLAG_NO_ALL_RESIDENT = 16, EVC_FLAG_PAIR_TILES = 32 };
 
 struct evc_solve_info;
 struct evc_dict;
@@ -165,7 +167,7 @@ enum {
     EVC_KERNEL_FUSED_WIDE = 6,  /* k_fused_wide: fused FACTORED for float32, 32 < M <= 208: task queue over (frame group, exemplar range) */
     EVC_KERNEL_FUSED_WIDE64 = 7, /* k_fused_wide64: the same for float64, 208 < M <= 528 (bins split over a workgroup's wavefronts) */
     EVC_KERNEL_FUSED_XY = 8     /* k_fused_xy: H and P register-resident, `members` workgroups per PAIR of frame tiles, the
-                                   exchange inside the sweeps (round 4; serves every M <= 32 shape with more than 256 exemplars) */
+                                   exchange phases inside the sweeps (round 4; on request only: EVC_FLAG_PAIR_TILES) */
 };
 
 typedef struct evc_solve_info {

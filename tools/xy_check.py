@@ -28,8 +28,8 @@ def case(M, N, T, K, l1=0.0, eps_mode="zero_replace", eps=None, seed=0, oracle=T
     if offs is not None:
         kw["utt_offsets"] = np.asarray(offs, dtype=np.int32)
     t0 = time.time()
-    H, info = evc.solve_activations(p["A"], p["X"], **kw)
-    H2, info2 = evc.solve_activations(p["A"], p["X"], pair_tiles=False, **kw)
+    H, info = evc.solve_activations(p["A"], p["X"], pair_tiles=True, **kw)
+    H2, info2 = evc.solve_activations(p["A"], p["X"], **kw)
     msg = f"M={M} N={N} T={T} K={K} l1={l1} {eps_mode}: {info['kernel']} x{info['members']} redo={info['redo']} | {info2['kernel']} x{info2['members']}"
     r2, z2 = rel(H, H2)
     msg += f" | vs k_fused_all {r2:.2e}"
