@@ -405,7 +405,7 @@ def main():
             "k_fused_mu": "k_fused_mu (persistent fused update, activations streamed)",
             "k_fused_wide": "k_fused_wide (fused FACTORED for M > 32: task queue over frame groups x exemplar ranges, "
                             "dictionary blocks shared through LDS, V resident per wavefront, H and P streamed once)",
-            "k_fused_wide64": "k_fused_wide64 (fused FACTORED for float64, 208 < M <= 576: the same task queue; a workgroup's "
+            "k_fused_wide64": "k_fused_wide64 (fused FACTORED for float64, 208 < M <= 528: the same task queue; a workgroup's "
                               "four wavefronts split the bins of 32 frames, fragments through per-wavefront LDS rings)",
             "k_gemm2": "k_gemm2 x2 per iteration (V = H Am^T, then the update as epilogue of V At^T)",
             "k_gemm_nt": "k_gemm_nt x2 per iteration (V = H Am^T, then the update as epilogue of V At^T)",
@@ -493,6 +493,28 @@ def main():
                 "H_max_rel_err_no_exchange_kernels": float(np.max(np.abs(Hb[nz] - act_cpu[nz]) / act_cpu[nz])),
                 "Y_max_rel_err": float(np.max(np.abs(Yg - Y_cpu) / np.abs(Y_cpu))),
                 "rtol_required": 1e-4, "sample_frames": Tc,
+            }
+            # ... and of the kernel that was TIMED, on the timed batch itself (the sample above is one utterance and may be
+            # routed to another kernel than the batch: VERDICT r03 item 2 v): the first frames of the batch's first
+            # utterance against the oracle started from that utterance's start value, plus Y = B H of the same frames
+            from oracle import evc_oracle as o_
+            step(False)
+            torch.cuda.synchronize()
+            S = int(min(48, lens[0]))
+            X0 = X[:lens[0]].double().cpu().numpy()                  # frames as rows
+            A64, B64 = A.double().cpu().numpy(), B.double().cpu().numpy()
+            h0 = float(np.sqrt(X0.mean() / N))
+            want = o_.mu_solve(np.ascontiguousarray(A64.T), np.ascontiguousarray(X0[:S].T), np.full((N, S), h0), K,
+                               eps_mode=o_.EPS_ZERO_REPLACE, eps=o_.SK_EPSILON, l1=l1, algo="factored")
+            got = H[:S].double().cpu().numpy().T
+            nzs = want != 0
+            floor = 1e-6 * float(np.abs(want).max())
+            big = np.abs(want) > floor
+            res["parity"]["timed_batch"] = {
+                "kernel": ktag, "frames": S,
+                "H_max_rel_err": float(np.max(np.abs(got[nzs] - want[nzs]) / np.abs(want[nzs]))),
+                "H_max_rel_err_above_1e-6_of_max": float(np.max(np.abs(got[big] - want[big]) / np.abs(want[big]))),
+                "Y_max_rel_err": float(np.max(np.abs(Yout[:S].double().cpu().numpy() - want.T @ B64) / np.abs(want.T @ B64))),
             }
             # latency of ONE utterance (device-resident inputs, solve + synthesis): the reference's call pattern
             n1 = min(Tu, T)

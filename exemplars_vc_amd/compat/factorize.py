@@ -66,9 +66,18 @@ def _factorize(X, W, beta_loss="kullback-leibler", tol=1e-4, *, device=None, alg
     return _factorize_impl(X, W, beta_loss, tol, device, algo, honor_beta_loss, hint, False)[0]
 
 
-def _factorize_impl(X, W, beta_loss, tol, device, algo, honor_beta_loss, hint, with_recon):
+def _factorize_impl(X, W, beta_loss, tol, device, algo, honor_beta_loss, hint, with_recon, warn_sink=None):
     """_factorize; with_recon: also H.T @ W (T x M), the reconstruction the WORLD branch's residual needs
-    (04_align_n_nmf.py:292-294), formed by the same launch sequence from the device-resident activations."""
+    (04_align_n_nmf.py:292-294), formed by the same launch sequence from the device-resident activations.
+    warn_sink: a list that receives (message, category) instead of warnings.warn - for callers on worker threads
+    (`warnings.catch_warnings` swaps process-global state and must not be entered from several threads at once);
+    the caller's thread issues them."""
+    def _warn(message, category, stacklevel):
+        if warn_sink is not None:
+            warn_sink.append((message, category))
+        else:
+            warnings.warn(message, category, stacklevel=stacklevel + 1)
+
     # 04_align_n_nmf.py:210 overrides `beta_loss` with "frobenius" whatever the caller passed;
     # honor_beta_loss=True runs the loss that was asked for (sklearn's KL update, SURVEY 8f-4)
     loss = beta_loss if honor_beta_loss else "frobenius"
@@ -83,9 +92,8 @@ def _factorize_impl(X, W, beta_loss, tol, device, algo, honor_beta_loss, hint, w
     if W.dtype != X.dtype:
         raise TypeError(f"H should have the same dtype as X. Got H.dtype = {W.dtype}.")
     if (X < 0).any():
-        warnings.warn("X has negative entries; the multiplicative update is only meaningful for "
-                      "non-negative data (scikit-learn does not check X on this route)",
-                      RuntimeWarning, stacklevel=2)
+        _warn("X has negative entries; the multiplicative update is only meaningful for "
+              "non-negative data (scikit-learn does not check X on this route)", RuntimeWarning, 2)
     kw = dict(layout="frame_major", iters=MAX_ITER, eps_mode="zero_replace", init="sklearn",
               check_every=CHECK_EVERY if tol > 0 else 0, stop_rule="sklearn" if tol > 0 else "none",
               tol=tol, algo=algo, device=device, info=True, loss=loss, cooperative=_exchange_allowed(hint))
@@ -95,15 +103,17 @@ def _factorize_impl(X, W, beta_loss, tol, device, algo, honor_beta_loss, hint, w
     else:
         act, info = solve_activations(W, X, **kw)
     if tol > 0 and int(info["n_iter"][0]) == MAX_ITER:
-        warnings.warn(f"Maximum number of iterations {MAX_ITER} reached. Increase it to improve "
-                      "convergence.", ConvergenceWarning, stacklevel=3)
+        _warn(f"Maximum number of iterations {MAX_ITER} reached. Increase it to improve convergence.",
+              ConvergenceWarning, 3)
     return act.T, recon
 
 
-def factorize_utterances(X_list, W, tol=1e-4, *, device=None, algo="auto", max_iter=MAX_ITER, hint="throughput"):
+def factorize_utterances(X_list, W, tol=1e-4, *, device=None, algo="auto", max_iter=MAX_ITER, hint="throughput",
+                         return_info=False):
     """`_factorize` for many utterances in ONE launch sequence: the frames are concatenated,
     the per-call semantics (initial value, stop test) are applied per utterance on the device.
-    Returns a list of (N x T_u) arrays and the per-utterance iteration counts."""
+    Returns a list of (N x T_u) arrays and the per-utterance iteration counts (return_info: also the solver's
+    info dict - which kernel carried the loop, redo, ...)."""
     X_list = [np.asarray(x) for x in X_list]
     W = _check_dictionary(W, X_list[0].shape[1])
     offs = np.concatenate([[0], np.cumsum([x.shape[0] for x in X_list])]).astype(np.int32)
@@ -112,7 +122,8 @@ def factorize_utterances(X_list, W, tol=1e-4, *, device=None, algo="auto", max_i
         W, X, layout="frame_major", iters=max_iter, eps_mode="zero_replace", init="sklearn",
         check_every=CHECK_EVERY if tol > 0 else 0, stop_rule="sklearn" if tol > 0 else "none",
         tol=tol, algo=algo, device=device, utt_offsets=offs, info=True, cooperative=_exchange_allowed(hint))
-    return [act[offs[i]:offs[i + 1]].T for i in range(len(X_list))], info["n_iter"]
+    out = [act[offs[i]:offs[i + 1]].T for i in range(len(X_list))]
+    return (out, info["n_iter"], info) if return_info else (out, info["n_iter"])
 
 
 def synthesize_rows(H, B, *, device=None):
@@ -212,16 +223,18 @@ def factorize(tobe_converted, src_feat, *, use_stft=True, tol=1e-4, device=None,
 _side_streams = {}      # (device index, slot) -> torch.cuda.Stream: reused, so that the solver's per-stream scratch is too
 
 
-def _factorize_recon(conv, A, tol, device, hint):
+def _factorize_recon(conv, A, tol, device, hint, warn_sink=None):
     """(H, H.T @ A) of one stream: `_factorize` plus the reconstruction, in one launch sequence (a seam of its own so
     that the host-logic tests can put the oracle in its place)"""
-    return _factorize_impl(conv, A, "frobenius", tol, device, "auto", False, hint, True)
+    return _factorize_impl(conv, A, "frobenius", tol, device, "auto", False, hint, True, warn_sink)
 
 
 def _solve_streams(streams, tol, device, hint, H_out):
     """solve every (conv, A) of `streams` concurrently: one host thread and one HIP stream each (the C ABI is
     thread-safe for distinct streams, include/evc.h); fills H_out['H_<name>'] and returns {name: H.T @ A}.
-    Warnings raised in the threads are re-issued by the caller's thread; the first exception is re-raised."""
+    The solves' warnings (ConvergenceWarning, negative X) are collected per stream and issued by the caller's thread
+    after the join - no thread enters `warnings.catch_warnings`, whose save / restore of the process-global filter list
+    is only correct when the exits are last-in-first-out; the first exception is re-raised."""
     import threading
     import torch
     from ..solver import require_device
@@ -240,10 +253,10 @@ def _solve_streams(streams, tol, device, hint, H_out):
             st = _side_streams.get((dev.index, slot))
             if st is None:
                 st = _side_streams[(dev.index, slot)] = torch.cuda.Stream(device=dev)
-            with torch.cuda.stream(st), warnings.catch_warnings(record=True) as rec:
-                warnings.simplefilter("always")
-                h, r = _factorize_recon(conv, A, tol, dev, hint)
-            H_out["H_" + name], recons[name], caught[name] = h, r, rec
+            sink = []
+            with torch.cuda.stream(st):
+                h, r = _factorize_recon(conv, A, tol, dev, hint, sink)
+            H_out["H_" + name], recons[name], caught[name] = h, r, sink
         except BaseException as e:  # noqa: BLE001 - handed to the caller's thread
             errors[name] = e
 
@@ -257,8 +270,8 @@ def _solve_streams(streams, tol, device, hint, H_out):
     for n in names:
         if n in errors:
             raise errors[n]
-        for wmsg in caught.get(n, ()):
-            warnings.warn_explicit(wmsg.message, wmsg.category, wmsg.filename, wmsg.lineno)
+        for message, category in caught.get(n, ()):
+            warnings.warn(message, category, stacklevel=3)
     return recons
 
 

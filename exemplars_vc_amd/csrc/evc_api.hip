@@ -535,6 +535,9 @@ constexpr int WIDE_MIN_TILES = 300;
 constexpr int WIDE64_MIN_TILES = 240, WIDE64_MAX_TILES = 1000;
 bool use_wide(int M, int N, int T_, int dtype, int algo, int loss, int reserved) {
     if (reserved & EVC_FLAG_NO_FUSED) return false;
+    // the task queues hand partial sums from workgroup to workgroup inside a launch and the call reads one word back at
+    // the end (a wait that ran out): exactly what EVC_FLAG_NO_EXCHANGE rules out
+    if (reserved & EVC_FLAG_NO_EXCHANGE) return false;
     const bool forced = ((reserved >> 8) & 0xff) != 0 || ((reserved >> 16) & 0xf) != 0;
     if (dtype == EVC_F64) {
         const int tiles = (T_ + 15) / 16;
@@ -559,7 +562,9 @@ int solve_wide(const T* A, int lda, const T* X, int ldx, T* H, int ldh, int M, i
     w.u.n_slots = n_slots;
     // tuning / tests: reserved bits 8..15 = exemplar ranges per frame group, bits 16..19 = wavefronts per workgroup
     const typename K::Layout fl = K::layout(M, N, T_, n_cus, (o.reserved >> 8) & 0xff, (o.reserved >> 16) & 0xf);
-    if (!wide_fits(fl, w.caps)) return ST_WORKSPACE;
+    // (a prepared dictionary holds the block images of the DEFAULT layout: a tuning override of the wavefront / tile
+    // count does not fit it - unsupported, not a workspace problem)
+    if (!wide_fits(fl, w.caps)) return (o.dict && ((o.reserved >> 16) & 0xf)) ? ST_UNSUPPORTED : ST_WORKSPACE;
 
     if (utt_offsets)
         HIP_TRY(hipMemcpyAsync(w.u.offsets, utt_offsets, sizeof(int) * (n_utt + 1), hipMemcpyHostToDevice, s));
@@ -595,7 +600,13 @@ int solve_wide(const T* A, int lda, const T* X, int ldx, T* H, int ldh, int M, i
 
     inf->kernel = K::kernel;
     inf->members = fl.c;
-    inf->exchange = fl.c > 1 ? 1 : 0;
+    inf->exchange = 1;               // tasks wait for tasks of other workgroups, whatever the number of ranges
+    // tests only (evc_solve_opts.test_abort_at, 0 in production): k > 0 raises the abort flag in front of the k-th
+    // launch of the iteration loop (-1: the call starts with it raised), as a wait that ran out would
+    const int fake_at = o.test_abort_at < 0 ? 0 : (o.test_abort_at > 0 ? o.test_abort_at : -1);
+    int* abort_w = reinterpret_cast<int*>(w.fb.ctl + 1);
+    if (fake_at == 0) HIP_TRY(hipMemsetAsync(abort_w, 1, sizeof(int), s));
+    int launch_no = 0;
     int next_it = 0;                 // first iteration not yet run (0 = the pass that forms P and V = A H0)
     auto run_to = [&](int it_end) -> int {      // iterations [next_it, it_end)
         if (it_end <= next_it) return 0;
@@ -621,6 +632,8 @@ int solve_wide(const T* A, int lda, const T* X, int ldx, T* H, int ldh, int M, i
         int n = o.iters - done;
         bool chk = false;
         if (o.check_every > 0 && n >= o.check_every) { n = o.check_every; chk = true; }
+        if (fake_at > 0 && launch_no == fake_at) HIP_TRY(hipMemsetAsync(abort_w, 1, sizeof(int), s));
+        ++launch_no;
         int st = run_to(done + n + 1);
         if (st) return st;
         done += n;
@@ -634,7 +647,17 @@ int solve_wide(const T* A, int lda, const T* X, int ldx, T* H, int ldh, int M, i
         if (st) return st;
     }
     if (o.ev_loop_stop) HIP_TRY(hipEventRecord((hipEvent_t)o.ev_loop_stop, s));
-    const int* abort = reinterpret_cast<const int*>(w.fb.ctl + 1);
+    // A bounded wait that ran out (a wedged or oversubscribed device) voids the solve: the flag is read back before
+    // anything reaches the caller's H or Y - one host round trip per solve, as for the other exchanging kernels
+    // (include/evc.h, Host synchronisation) - and the caller of this function redoes the solve on the two contractions
+    // from the untouched inputs.  (Round 3 exported NaN under status 0.)
+    {
+        int aborted = 0;
+        HIP_TRY(hipMemcpyAsync(&aborted, abort_w, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (aborted) return ST_COOP_TIMEOUT;
+    }
+    const int* abort = abort_w;
     if (H) HIP_TRY(wide_export_h(fl, w.fb.Hw, H, ldh, fm ? 1 : 0, T_, N, abort, s));
     if (y) {
         HIP_TRY(wide_export_h(fl, w.fb.Hw, w.H0, d.Np, 1, T_, N, abort, s));
@@ -1051,24 +1074,50 @@ static int solve_checked(const void* A, int lda, const void* X, int ldx, void* H
     } else if (n_utt != 1) {
         return ST_BADARG;
     }
+    {   // tuning bits 16..19: wavefronts per workgroup of k_fused_wide (4 | 8), whole bin tiles per wavefront of
+        // k_fused_wide64 (4 | 5 | 7 | 8: the narrowest instance >= the request that holds M); anything else is an error
+        const int tw = (o.reserved >> 16) & 0xf;
+        if (M > 32 && tw != 0 && !(o.dtype == EVC_F32 ? (tw == 4 || tw == 8) : (tw == 4 || tw == 5 || tw == 7 || tw == 8)))
+            return ST_BADARG;
+    }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     evc_solve_info inf{};
     int st;
     const int algo_eff = o.algo == EVC_ALGO_AUTO ? EVC_ALGO_FACTORED : o.algo;
-    if (o.dtype == EVC_F64 && use_wide(M, N, T, o.dtype, algo_eff, o.loss, o.reserved))
+    // a task-queue solve whose bounded wait ran out is redone on the two contractions (nothing has reached H or Y)
+    evc_solve_opts redo_o = o;
+    redo_o.reserved |= EVC_FLAG_NO_FUSED;
+    redo_o.test_abort_at = 0;
+    if (o.dtype == EVC_F64 && use_wide(M, N, T, o.dtype, algo_eff, o.loss, o.reserved)) {
         st = solve_wide<double>(static_cast<const double*>(A), lda, static_cast<const double*>(X), ldx,
                                 static_cast<double*>(H), ldh, M, N, T, utt_offsets, n_utt, o, workspace, workspace_bytes,
                                 n_iter_out, err_out, y, s, &inf);
-    else if (o.dtype == EVC_F64)
+        if (st == ST_COOP_TIMEOUT) {
+            const int launches = inf.launches;
+            inf = evc_solve_info{};
+            st = solve_typed<double>(A, lda, X, ldx, H, ldh, M, N, T, utt_offsets, n_utt, redo_o, workspace,
+                                     workspace_bytes, n_iter_out, err_out, y, s, &inf);
+            inf.redo = 1;
+            inf.launches += launches;
+        }
+    } else if (o.dtype == EVC_F64)
         st = solve_typed<double>(A, lda, X, ldx, H, ldh, M, N, T, utt_offsets, n_utt, o, workspace,
                                  workspace_bytes, n_iter_out, err_out, y, s, &inf);
     else if (f32_rides_f64(M, N, T, o.algo, o.reserved))
         st = solve_f32_on_f64(A, lda, X, ldx, H, ldh, M, N, T, utt_offsets, n_utt, o, workspace, workspace_bytes,
                               n_iter_out, err_out, y, s, &inf);
-    else if (use_wide(M, N, T, o.dtype, algo_eff, o.loss, o.reserved))
+    else if (use_wide(M, N, T, o.dtype, algo_eff, o.loss, o.reserved)) {
         st = solve_wide<float>(static_cast<const float*>(A), lda, static_cast<const float*>(X), ldx, static_cast<float*>(H),
                         ldh, M, N, T, utt_offsets, n_utt, o, workspace, workspace_bytes, n_iter_out, err_out, y, s, &inf);
-    else
+        if (st == ST_COOP_TIMEOUT) {
+            const int launches = inf.launches;
+            inf = evc_solve_info{};
+            st = solve_typed<float>(A, lda, X, ldx, H, ldh, M, N, T, utt_offsets, n_utt, redo_o, workspace,
+                                    workspace_bytes, n_iter_out, err_out, y, s, &inf);
+            inf.redo = 1;
+            inf.launches += launches;
+        }
+    } else
         st = solve_typed<float>(A, lda, X, ldx, H, ldh, M, N, T, utt_offsets, n_utt, o, workspace,
                                 workspace_bytes, n_iter_out, err_out, y, s, &inf);
     if (o.info && o.info->struct_bytes == (int)sizeof(evc_solve_info)) {

@@ -33,7 +33,12 @@
  *         the cooperative k_fused_res launch for one or two utterances): one round trip at the end
  *         of the call reads the flag that tells whether a workgroup gave up waiting for its peers (then
  *         the solve is redone without any exchange).  EVC_FLAG_NO_EXCHANGE keeps such a call fully
- *         asynchronous (at about half the speed for a lone utterance, ~10 % less for large batches).
+ *         asynchronous (at about half the speed for a lone utterance, ~10 % less for large batches);
+ *     (3) evc_nmf_solve / evc_nmf_convert on the task-queue kernels for wide spectra (k_fused_wide: float32,
+ *         32 < M <= 208, batches from ~7 utterances on; k_fused_wide64: float64, 208 < M <= 528, 6 .. ~20 utterances):
+ *         the same round trip, taken BEFORE anything is written to H or Y, so that a solve whose wait ran out is
+ *         redone on the two-contraction path from the untouched inputs (evc_solve_info.redo = 1).  Round 3 delivered
+ *         NaN under status 0 there.  EVC_FLAG_NO_EXCHANGE routes away from these kernels too.
  *   No global mutable state: calls on distinct streams/devices are independent and the
  *   caller's current device (hipSetDevice) is honoured.  Nothing is read from the process environment.
  *   Host arrays (utt_offsets, frame_offsets, a_offsets / b_offsets) are consumed before the call returns: they are
@@ -107,7 +112,8 @@ enum { EVC_LOSS_FROBENIUS = 0, EVC_LOSS_KL = 1 };
  *   NO_FUSED         the generic two-contraction path instead of the fused persistent kernels (M <= 32)
  *   EXACT_DIV        correctly rounded quotients in the fused float64 kernels (always on with EVC_STOP_PYMF;
  *                    else a shared / refined reciprocal, <= 2 ulp)
- *   NO_EXCHANGE      no kernel in which workgroups exchange data inside a launch: the call is then fully
+ *   NO_EXCHANGE      no kernel in which workgroups exchange data inside a launch (k_fused_all with more than one member,
+ *                    cooperative k_fused_res, the task queues k_fused_wide / k_fused_wide64): the call is then fully
  *                    asynchronous (see "Host synchronisation" above); a latency / determinism knob
  *   NO_ALL_RESIDENT  keep k_fused_all out (k_fused_res, with its cooperative launch for few frame tiles)
  *   PAIR_TILES       tuning / experiments: k_fused_xy (two frame tiles per member, exchange phases inside the sweeps)
@@ -129,8 +135,9 @@ typedef struct evc_solve_opts {
     int reserved;      /* flags, 0 = defaults: an OR of EVC_FLAG_* (below); bits 8..15: tuning only - M <= 32: 1 | 2 force
                           the general streamed kernel with that many frame tiles per workgroup; M > 32: that many exemplar
                           ranges per frame group in k_fused_wide / k_fused_wide64, whatever the batch size; bits 16..19,
-                          tuning only: k_fused_wide with 4 | 8 wavefronts per workgroup, k_fused_wide64 with >= 5 | 7 | 9
-                          bin tiles per wavefront */
+                          tuning only: k_fused_wide with 4 | 8 wavefronts per workgroup, k_fused_wide64 with at least 4 | 5 | 7 | 8
+                          whole bin tiles per wavefront (the narrowest instance that holds M); other values: status -1; with
+                          a prepared dictionary whose images do not fit the override: status -3 */
     int loss;          /* EVC_LOSS_* */
     int test_abort_at; /* 0 in production.  Tests only: k > 0 pretends, in front of the k-th launch of the iteration
                           loop, that a workgroup gave up waiting for its peers (the abort flag is raised as a timed-out

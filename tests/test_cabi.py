@@ -45,7 +45,7 @@ def test_struct_mirror_matches_header_fields():
     # kernel ids of the header <-> the names the Python side reports
     ids = dict((n.lower(), int(v)) for n, v in re.findall(r"EVC_KERNEL_([A-Z_0-9]+) = (\d+)", hdr))
     assert ids == {"none": 0, "gemm_nt": 1, "gemm2": 2, "fused_mu": 3, "fused_res": 4, "fused_all": 5, "fused_wide": 6,
-                   "fused_wide64": 7}
+                   "fused_wide64": 7, "fused_xy": 8}
     assert all(_lib.KERNEL_NAMES[v] in ("none", "k_" + n) for n, v in ids.items())
 
 

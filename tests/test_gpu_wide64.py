@@ -147,12 +147,18 @@ def test_generic_path_gate_after_every_utterance_stopped(dtype, M, kernel):
         for u in range(len(offs) - 1):
             a, b = offs[u], offs[u + 1]
             act, n_ref, _ = o.sklearn_mu_fixed_dictionary(X64[a:b], W64, 120, 5e-3)
+            n_got = int(info["n_iter"][u])
             if dtype == np.float64:
-                assert int(info["n_iter"][u]) == n_ref
+                assert n_got == n_ref
+            else:
+                # a float32 residual can cross the threshold one check earlier or later than the float64 oracle's:
+                # within one check, and the activations are compared with the oracle run for exactly n_got iterations
+                assert abs(n_got - n_ref) <= 10, (n_got, n_ref)
+                if n_got != n_ref:
+                    act, _, _ = o.sklearn_mu_fixed_dictionary(X64[a:b], W64, n_got, 0.0)
             got = H[a:b].astype(np.float64)
-            if int(info["n_iter"][u]) == n_ref:
-                np.testing.assert_allclose(got, act, atol=eps32["atol"] * float(np.abs(act).max()) if dtype == np.float32 else 0.0,
-                                           rtol=eps32["rtol"])
+            np.testing.assert_allclose(got, act, atol=eps32["atol"] * float(np.abs(act).max()) if dtype == np.float32 else 0.0,
+                                       rtol=eps32["rtol"])
 
 
 @pytest.mark.parametrize("seed", range(14))

@@ -49,6 +49,16 @@ def test_pymf_restatement_is_bit_exact(path):
         np.testing.assert_allclose(o.pymf_frobenius(g["data"], g["W"], H), float(g["frobenius_norm"]), rtol=1e-15)
 
 
+@pytest.mark.parametrize("path", golden_files("pymfw_"), ids=os.path.basename)
+def test_pymf_default_call_restatement_is_bit_exact(path):
+    """factorize() with pymf's defaults (compute_w=True): the vendored pymf's W, H and ferr, bit for bit"""
+    g = load_golden(path)
+    W, H, ferr = o.pymf_factorize_full(g["data"], g["W0"], g["H0"], int(g["niter"]), bool(g["compute_err"]))
+    assert np.array_equal(W, g["W"]) and np.array_equal(H, g["H"])
+    if bool(g["compute_err"]):
+        assert np.array_equal(ferr, g["ferr"])
+
+
 def test_pymf_doctest_known_answer():
     """pymf/nmf.py:57-63 - the reference's only known answer on the fixed-dictionary path."""
     data = np.array([[1.5], [1.2]])

@@ -130,6 +130,23 @@ def pymf_case(NMF, name, M, N, T, seed, niter, compute_err, data=None, W=None, H
     print(f"{name}: M={data.shape[0]} T={data.shape[1]} N={W.shape[1]} len(ferr)={len(ferr)}")
 
 
+def pymf_full_case(NMF, name, M, N, T, seed, niter, compute_err):
+    """pymf's DEFAULT call, factorize(compute_w=True): dictionary and activations updated in turn (base.py:238-270,
+    nmf.py:66-76).  Outside the accelerated path; the fixture pins compat.pymf's host-side dictionary update."""
+    A, B, X = synth(M, N, T, seed)
+    rng = np.random.default_rng(seed + 1)
+    W0 = rng.random((M, N)) + 1e-4
+    H0 = rng.random((N, T)) + 1e-4
+    mdl = NMF(X.copy(), num_bases=N)
+    mdl.W = W0.copy()
+    mdl.H = H0.copy()
+    mdl.factorize(niter=niter, compute_w=True, compute_err=compute_err)
+    ferr = np.asarray(mdl.ferr) if compute_err else np.zeros(0)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), surface="pymf_full", data=X, W0=W0, H0=H0, W=mdl.W, H=mdl.H,
+                        niter=niter, compute_err=compute_err, ferr=ferr)
+    print(f"{name}: M={M} T={T} N={N} len(ferr)={len(ferr)}")
+
+
 def read_wav(path):
     with wave.open(path) as w:
         assert w.getsampwidth() == 2 and w.getnchannels() == 1
@@ -219,6 +236,8 @@ def main():
     pymf_case(NMF, "pymf_m40_n24_t19_k400_err", 40, 24, 19, 202, niter=400, compute_err=True)
     pymf_case(NMF, "pymf_doctest_kat", 0, 0, 0, 0, niter=20, compute_err=True,
               data=np.array([[1.5], [1.2]]), W=np.array([[1.0, 0.0], [0.0, 1.0]]), H0=None)
+    pymf_full_case(NMF, "pymfw_m25_n12_t40_k30_err", 25, 12, 40, 401, niter=30, compute_err=True)
+    pymf_full_case(NMF, "pymfw_m25_n12_t40_k30_noerr", 25, 12, 40, 401, niter=30, compute_err=False)
 
 
 if __name__ == "__main__":
