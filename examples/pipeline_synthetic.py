@@ -87,6 +87,19 @@ def main(n_pairs=6, seconds=1.0, gl_iters=60, verbose=True):
             H, R = fz.factorize(tobe, aligned_src, use_stft=True, cache_dir=root)
         converted = fz.convert(H, aligned_tar, residual=R, use_stft=True)
         t_conv = time.perf_counter() - t1
+        # the same dictionary built in one pass on the GPU (DTW paths consumed on the device, aligned frames gathered
+        # there, images prepared once): what a caller converting many utterances would hold
+        from exemplars_vc_amd import convert as evc_convert
+        t3 = time.perf_counter()
+        pd, rows = make_dict.aligned_dictionary([band_log_mag(f["stft"]).T for f in src_feat],
+                                                [band_log_mag(f["stft"]).T for f in tar_feat], src_feat, tar_feat)
+        t_pd = time.perf_counter() - t3
+        assert int(rows[-1]) == N
+        H_d, Y_d = evc_convert(pd, np.abs(np.asarray(tobe["real"])).astype(H["H_stft"].dtype), layout="frame_major",
+                               iters=150, eps_mode="zero_replace", init="sklearn", check_every=10, stop_rule="sklearn",
+                               tol=1e-4)
+        assert np.allclose(Y_d, converted, rtol=1e-3, atol=1e-6 * float(np.abs(converted).max()))
+        say(f"dictionary on the device (DTW + gather + prepare, no frame leaves the GPU): {t_pd * 1e3:.1f} ms")
         np.random.seed(0)
         t2 = time.perf_counter()
         wav, wav_path = griffin_lim.synthesize2(converted, FS, "converted", out_dir=os.path.join(root, "wav"),

@@ -26,7 +26,8 @@ SYMBOLS = ("evc_version", "evc_strerror", "evc_device_count", "evc_workspace_byt
            "evc_nmf_solve", "evc_nmf_convert", "evc_synthesize", "evc_residual",
            "evc_griffin_lim_workspace_bytes", "evc_griffin_lim", "evc_griffin_lim_batch_workspace_bytes",
            "evc_griffin_lim_batch", "evc_dtw_workspace_bytes", "evc_dtw_align",
-           "evc_stft_frames", "evc_stft_workspace_bytes", "evc_stft", "evc_dict_bytes", "evc_dict_prepare")
+           "evc_stft_frames", "evc_stft_workspace_bytes", "evc_stft", "evc_dict_bytes", "evc_dict_prepare",
+           "evc_dtw_path_rows", "evc_dtw_gather_rows")
 
 
 class SolveOpts(C.Structure):
@@ -144,6 +145,11 @@ def lib():
     L.evc_dtw_align.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.POINTER(C.c_int),
                                 C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_size_t, C.c_void_p]
+    L.evc_dtw_path_rows.restype = C.c_int
+    L.evc_dtw_path_rows.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_void_p]
+    L.evc_dtw_gather_rows.restype = C.c_int
+    L.evc_dtw_gather_rows.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_void_p]
     _lib = L
     return L
 

@@ -1297,4 +1297,35 @@ int evc_dtw_align(const void* A, int lda, const int* a_offsets, const void* B, i
                         reinterpret_cast<hipStream_t>(stream));
 }
 
+
+int evc_dtw_path_rows(const int* path_len, int n_pairs, int* row_start, int* n_rows_out, evc_stream_t stream) {
+    if (!path_len || !row_start || n_pairs < 1 || n_pairs > 65535) return ST_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    HIP_TRY(dtw_path_scan(path_len, n_pairs, row_start, s));
+    if (n_rows_out) {
+        HIP_TRY(hipMemcpyAsync(n_rows_out, row_start + n_pairs, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return ST_OK;
+}
+
+int evc_dtw_gather_rows(const void* src, long ld_src, int elem_stride, const int* path, const int* path_len,
+                        const int* src_offsets, const int* pair_offsets, const int* row_start, int n_pairs, int cols,
+                        int op, void* dst, long ld_dst, int dtype, evc_stream_t stream) {
+    if (!src || !path || !path_len || !src_offsets || !pair_offsets || !row_start || !dst) return ST_BADARG;
+    if (n_pairs < 1 || n_pairs > 65535 || cols < 1 || elem_stride < 1 || ld_dst < cols) return ST_BADARG;
+    if (ld_src < (long)(cols - 1) * elem_stride + 1) return ST_BADARG;
+    if (op != EVC_GATHER_COPY && op != EVC_GATHER_ABS) return ST_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == EVC_F64)
+        HIP_TRY(dtw_gather<double>(static_cast<const double*>(src), ld_src, elem_stride, path, path_len, src_offsets,
+                                   pair_offsets, row_start, n_pairs, cols, op, static_cast<double*>(dst), ld_dst, s));
+    else if (dtype == EVC_F32)
+        HIP_TRY(dtw_gather<float>(static_cast<const float*>(src), ld_src, elem_stride, path, path_len, src_offsets,
+                                  pair_offsets, row_start, n_pairs, cols, op, static_cast<float*>(dst), ld_dst, s));
+    else
+        return ST_BADARG;
+    return ST_OK;
+}
+
 }  // extern "C"

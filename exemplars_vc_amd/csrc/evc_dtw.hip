@@ -318,4 +318,76 @@ hipError_t dtw_run(const double* A, long lda, const int* aoff, const double* B, 
     return hipGetLastError();
 }
 
+
+// ----------------------------------------------------------------------------------------------------------------
+// Gather of the aligned frames (04_align_n_nmf.py:100-169, align_sp_ap_f0): the dictionary rows are the frames the DTW
+// paths name, pair after pair.  Round 3 downloaded the paths and gathered with numpy; here the paths never leave the
+// device: an exclusive scan of the path lengths gives every pair its first dictionary row, then one kernel copies rows.
+// ----------------------------------------------------------------------------------------------------------------
+// row_start[p] = sum of path_len[q], q < p; row_start[n_pairs] = N (one workgroup: n_pairs <= 65535)
+__global__ __launch_bounds__(1024) void k_path_scan(const int* __restrict__ path_len, int n_pairs, int* __restrict__ row_start) {
+    __shared__ int s_part[1024];
+    const int tid = threadIdx.x;
+    const int per = (n_pairs + 1023) / 1024;
+    int sum = 0;
+    for (int i = tid * per; i < min(n_pairs, (tid + 1) * per); ++i) sum += path_len[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int v = tid >= o ? s_part[tid - o] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int run = tid ? s_part[tid - 1] : 0;
+    for (int i = tid * per; i < min(n_pairs, (tid + 1) * per); ++i) {
+        row_start[i] = run;
+        run += path_len[i];
+    }
+    if (tid == 1023) row_start[n_pairs] = s_part[1023];
+}
+
+// dst[row_start[p] + k][c] = op(src[src_off[p] + path[pair_off[p] + k]][c * elem_stride]), k < path_len[p].
+// One workgroup row of 256 threads walks the columns; blockIdx.y strides over the rows of pair blockIdx.z.
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather_pairs(const T* __restrict__ src, long ld_src, int elem_stride,
+                                                      const int* __restrict__ path, const int* __restrict__ path_len,
+                                                      const int* __restrict__ src_off, const int* __restrict__ pair_off,
+                                                      const int* __restrict__ row_start, int cols, int op,
+                                                      T* __restrict__ dst, long ld_dst) {
+    const int p = blockIdx.z;
+    const int len = path_len[p];
+    const long d0 = row_start[p];
+    const int* pp = path + pair_off[p];
+    const long s0 = src_off[p];
+    for (int k = blockIdx.y; k < len; k += gridDim.y) {
+        const T* srow = src + (s0 + pp[k]) * ld_src;
+        T* drow = dst + (d0 + k) * ld_dst;
+        for (int c = blockIdx.x * 256 + threadIdx.x; c < cols; c += gridDim.x * 256) {
+            T v = srow[(long)c * elem_stride];
+            if (op == 1) v = v < T(0) ? -v : v;          // |.|  (NaN stays NaN, -0 -> 0 like np.abs)
+            drow[c] = v;
+        }
+    }
+}
+
+hipError_t dtw_path_scan(const int* path_len, int n_pairs, int* row_start, hipStream_t s) {
+    hipLaunchKernelGGL(k_path_scan, dim3(1), dim3(1024), 0, s, path_len, n_pairs, row_start);
+    return hipGetLastError();
+}
+
+template <typename T>
+hipError_t dtw_gather(const T* src, long ld_src, int elem_stride, const int* path, const int* path_len, const int* src_off,
+                      const int* pair_off, const int* row_start, int n_pairs, int cols, int op, T* dst, long ld_dst,
+                      hipStream_t s) {
+    const unsigned gx = (unsigned)((cols + 255) / 256);
+    hipLaunchKernelGGL((k_gather_pairs<T>), dim3(gx > 4 ? 4 : gx, 64, (unsigned)n_pairs), dim3(256), 0, s, src, ld_src,
+                       elem_stride, path, path_len, src_off, pair_off, row_start, cols, op, dst, ld_dst);
+    return hipGetLastError();
+}
+template hipError_t dtw_gather<double>(const double*, long, int, const int*, const int*, const int*, const int*, const int*,
+                                       int, int, int, double*, long, hipStream_t);
+template hipError_t dtw_gather<float>(const float*, long, int, const int*, const int*, const int*, const int*, const int*,
+                                      int, int, int, float*, long, hipStream_t);
+
 }  // namespace evc

@@ -306,5 +306,11 @@ int dtw_max_frames();
 hipError_t dtw_run(const double* A, long lda, const int* aoff, const double* B, long ldb, const int* boff,
                    int D, int n_pairs, int* path_a, int* path_b, int* path_len, double* total, void* ws,
                    hipStream_t s);
+// aligned-frame gather (evc_dtw.hip): exclusive scan of the path lengths, then rows by the paths
+hipError_t dtw_path_scan(const int* path_len, int n_pairs, int* row_start, hipStream_t s);
+template <typename T>
+hipError_t dtw_gather(const T* src, long ld_src, int elem_stride, const int* path, const int* path_len, const int* src_off,
+                      const int* pair_off, const int* row_start, int n_pairs, int cols, int op, T* dst, long ld_dst,
+                      hipStream_t s);
 
 }  // namespace evc

@@ -179,6 +179,10 @@ def prepare_dictionary(A, B=None, *, layout="bin_major", dtype=None, loss="frobe
                                 buf.data_ptr() + off, nbytes, C.byref(handle),
                                 C.c_void_p(torch.cuda.current_stream(device).cuda_stream))
     _lib.check(st, "evc_dict_prepare")
+    # evc.h promises the images to later calls on the SAME stream only; a prepared dictionary is used from side streams
+    # and other host threads (compat's three WORLD streams, cached_dictionary hits), so the packing kernels are waited
+    # for here, once per dictionary
+    torch.cuda.current_stream(device).synchronize()
     return PreparedDictionary(handle, buf, lay, tdtype, dcode, device, lcode, float(eps))
 
 
@@ -546,6 +550,88 @@ def stft(y, n_fft=400, hop_length=80, *, center=True, device=None):
                             ws.data_ptr(), ws.numel(), C.c_void_p(stream))
         _lib.check(st, "evc_stft")
     return (re.cpu().numpy(), im.cpu().numpy()) if was_np else (re, im)
+
+
+def dtw_dictionary(dtw_a, dtw_b, src_feats, tar_feats, *, op="copy", real_part=False, dtype=None, device=None):
+    """DTW alignment of parallel utterance pairs AND the gather of the aligned frames, on the GPU with no round trip of
+    frames through the host (01_make_dict_parallel.py:215-249, 04_align_n_nmf.py:100-169,230-246,320-324): the paths stay
+    on the device, an exclusive scan of their lengths places every pair in the dictionary, one kernel copies the rows.
+
+      dtw_a[p], dtw_b[p]        : (frames, features) float64 - what the alignment is computed on (the script: MFCCs)
+      src_feats[p], tar_feats[p]: (frames_a, cols) / (frames_b, cols_b) - the frames the dictionary is made of; complex
+                                  arrays with real_part=True contribute their real parts (the script's `real`)
+      op                        : "copy" | "abs" (the STFT flow stacks np.abs of the real parts, :320-324)
+    Returns (A, B, row_start): device tensors N x cols and N x cols_b (frames / exemplars as rows, the orientation
+    `prepare_dictionary(layout="frame_major")` and the solver take) and the first row of every pair (numpy, n_pairs + 1).
+    Only N (one int) is read back - it sizes the dictionary."""
+    torch = _torch()
+    device = require_device(device)
+    L = _lib.lib()
+    n = len(dtw_a)
+    if n == 0 or not (len(dtw_b) == len(src_feats) == len(tar_feats) == n):
+        raise ValueError("need the same, non-zero number of utterances in every list")
+    dtw_a = [np.ascontiguousarray(np.asarray(f, dtype=np.float64)) for f in dtw_a]
+    dtw_b = [np.ascontiguousarray(np.asarray(f, dtype=np.float64)) for f in dtw_b]
+    D = dtw_a[0].shape[1]
+    if any(f.ndim != 2 or f.shape[1] != D for f in dtw_a + dtw_b):
+        raise ValueError("every utterance must be (frames, features) with the same number of features")
+    for fa, fb, sa, sb in zip(dtw_a, dtw_b, src_feats, tar_feats):
+        if len(sa) != len(fa) or len(sb) != len(fb):
+            raise ValueError("alignment features and dictionary frames must have the same number of frames per utterance")
+    aoff = np.concatenate([[0], np.cumsum([len(f) for f in dtw_a])]).astype(np.int32)
+    boff = np.concatenate([[0], np.cumsum([len(f) for f in dtw_b])]).astype(np.int32)
+
+    def stack(feats):
+        m = np.concatenate([np.asarray(f) for f in feats], axis=0)
+        if np.iscomplexobj(m):
+            if not real_part:
+                raise ValueError("complex frames need real_part=True")
+            base = np.float32 if m.dtype == np.complex64 else np.float64
+            v = np.ascontiguousarray(m).view(base)                 # interleaved re / im: the kernel strides by 2
+            return v, 2, m.shape[1]
+        base = np.float32 if (m.dtype == np.float32 and dtype != "f64") else np.float64
+        return np.ascontiguousarray(m.astype(base, copy=False)), 1, m.shape[1]
+
+    sa, stride_a, cols_a = stack(src_feats)
+    sb, stride_b, cols_b = stack(tar_feats)
+    if sa.dtype != sb.dtype:
+        sa, sb = sa.astype(np.float64), sb.astype(np.float64)
+    tdt = torch.float64 if sa.dtype == np.float64 else torch.float32
+    dcode = _lib.F64 if sa.dtype == np.float64 else _lib.F32
+    opc = {"copy": 0, "abs": 1}[op]
+    ap, bp = aoff.ctypes.data_as(C.POINTER(C.c_int)), boff.ctypes.data_as(C.POINTER(C.c_int))
+    ws_bytes = int(L.evc_dtw_workspace_bytes(ap, bp, n))
+    if ws_bytes == 0:
+        raise ValueError("utterance too long for the DTW kernel's wavefront buffers")
+    cap = int(aoff[-1] + boff[-1])
+    with torch.cuda.device(device):
+        FA = torch.from_numpy(np.concatenate(dtw_a, axis=0)).to(device)
+        FB = torch.from_numpy(np.concatenate(dtw_b, axis=0)).to(device)
+        SA, SB = torch.from_numpy(sa).to(device), torch.from_numpy(sb).to(device)
+        pa = torch.empty(max(cap, 1), dtype=torch.int32, device=device)
+        pb = torch.empty(max(cap, 1), dtype=torch.int32, device=device)
+        plen = torch.empty(n, dtype=torch.int32, device=device)
+        rows = torch.empty(n + 1, dtype=torch.int32, device=device)
+        d_aoff = torch.from_numpy(aoff[:-1].copy()).to(device)
+        d_boff = torch.from_numpy(boff[:-1].copy()).to(device)
+        d_poff = torch.from_numpy((aoff[:-1] + boff[:-1]).astype(np.int32)).to(device)
+        stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        with _workspace(ws_bytes, device) as ws:
+            st = L.evc_dtw_align(FA.data_ptr(), D, ap, FB.data_ptr(), D, bp, D, n, pa.data_ptr(), pb.data_ptr(),
+                                 plen.data_ptr(), None, ws.data_ptr(), ws.numel(), stream)
+        _lib.check(st, "evc_dtw_align")
+        n_rows = C.c_int(0)
+        _lib.check(L.evc_dtw_path_rows(plen.data_ptr(), n, rows.data_ptr(), C.byref(n_rows), stream), "evc_dtw_path_rows")
+        N = int(n_rows.value)
+        A = torch.empty((N, cols_a), dtype=tdt, device=device)
+        B = torch.empty((N, cols_b), dtype=tdt, device=device)
+        _lib.check(L.evc_dtw_gather_rows(SA.data_ptr(), SA.shape[1], stride_a, pa.data_ptr(), plen.data_ptr(),
+                                         d_aoff.data_ptr(), d_poff.data_ptr(), rows.data_ptr(), n, cols_a, opc,
+                                         A.data_ptr(), cols_a, dcode, stream), "evc_dtw_gather_rows")
+        _lib.check(L.evc_dtw_gather_rows(SB.data_ptr(), SB.shape[1], stride_b, pb.data_ptr(), plen.data_ptr(),
+                                         d_boff.data_ptr(), d_poff.data_ptr(), rows.data_ptr(), n, cols_b, opc,
+                                         B.data_ptr(), cols_b, dcode, stream), "evc_dtw_gather_rows")
+    return A, B, rows.cpu().numpy()
 
 
 def dtw_align(feats_a, feats_b, *, device=None, want_cost=False):

@@ -16,6 +16,7 @@
  *   evc_griffin_lim replaces reconstruct_signal_griffin_lim()  zz_audio_utilities.py:258-292
  *   evc_stft        replaces librosa.core.stft(...) of 04_align_n_nmf.py:422
  *   evc_dtw_align   replaces _dtw_alignment() / dtw_alignment()  01_make_dict_parallel.py:215-249
+ *   evc_dtw_path_rows, evc_dtw_gather_rows  replace align_sp_ap_f0() + the stacking  04_align_n_nmf.py:100-169,230-246
  *   evc_residual    replaces sklearn _beta_divergence(beta=2, square_root=True)
  *                   (_nmf.py:85-135) and pymf frobenius_norm (pymf/base.py:144-165)
  *
@@ -326,6 +327,28 @@ size_t evc_dtw_workspace_bytes(const int* a_offsets, const int* b_offsets, int n
 int evc_dtw_align(const void* A, int lda, const int* a_offsets, const void* B, int ldb,
                   const int* b_offsets, int D, int n_pairs, int* path_a, int* path_b, int* path_len,
                   double* total, void* workspace, size_t workspace_bytes, evc_stream_t stream);
+
+
+/* Gather of the aligned frames - align_sp_ap_f0(), 04_align_n_nmf.py:100-169, and the stacking of the aligned frames
+ * into the dictionary, :230-246,320-324,350-361: the dictionary's rows are the frames the DTW paths name, pair after
+ * pair.  With these two calls the paths evc_dtw_align left on the device are consumed there: the feature frames make no
+ * round trip through the host, only the number of rows N (one int) comes back, because N sizes the dictionary.
+ *
+ * evc_dtw_path_rows: row_start[p] = first dictionary row of pair p (exclusive scan of path_len), row_start[n_pairs] = N.
+ *   path_len   : device, n_pairs ints (evc_dtw_align)          row_start : device, n_pairs + 1 ints
+ *   n_rows_out : host int or NULL; non-NULL makes the call synchronous (it returns N)
+ * evc_dtw_gather_rows: dst[row_start[p] + k][c] = op(src[src_offsets[p] + path[pair_offsets[p] + k]][c * elem_stride])
+ *   for k < path_len[p], c < cols.
+ *   src          : frames as rows, row stride ld_src (elements); elem_stride = 2 picks the real parts of an interleaved
+ *                  complex matrix (the script's np.abs(real(stft)), :320-324, with op = EVC_GATHER_ABS)
+ *   path         : device, path_a or path_b of evc_dtw_align;  pair_offsets : device, n_pairs ints, a_offsets[p] + b_offsets[p]
+ *   src_offsets  : device, n_pairs ints, first row of pair p's utterance in src
+ *   dst          : N x cols, row stride ld_dst;  dtype: EVC_F64 | EVC_F32 (src and dst alike) */
+enum { EVC_GATHER_COPY = 0, EVC_GATHER_ABS = 1 };
+int evc_dtw_path_rows(const int* path_len, int n_pairs, int* row_start, int* n_rows_out, evc_stream_t stream);
+int evc_dtw_gather_rows(const void* src, long ld_src, int elem_stride, const int* path, const int* path_len,
+                        const int* src_offsets, const int* pair_offsets, const int* row_start, int n_pairs, int cols,
+                        int op, void* dst, long ld_dst, int dtype, evc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -97,3 +97,43 @@ def test_corpus_sized_batch():
         if k in (0, 80):
             _, (qa, qb) = o.dtw_align(a, b)
             assert np.array_equal(pa, qa) and np.array_equal(pb, qb)
+
+
+def test_dictionary_built_on_the_device_equals_the_host_gather():
+    """evc_dtw_path_rows + evc_dtw_gather_rows (compat.make_dict.aligned_dictionary): the aligned frames gathered on the
+    device by the paths evc_dtw_align left there - bit for bit what align_sp_ap_f0 + the stacking of factorize() /
+    convert() produce through host lists (04_align_n_nmf.py:100-169,230-246,320-324), for the STFT flow (|real| of complex
+    frames) and for a WORLD stream; a solve from the prepared dictionary equals the solve from the host-built arrays."""
+    import exemplars_vc_amd as evc
+    from exemplars_vc_amd.compat import make_dict
+    rng = np.random.default_rng(11)
+    n_pairs, order = 7, 13
+    la = [int(v) for v in rng.integers(30, 140, n_pairs)]
+    lb = [int(v) for v in rng.integers(30, 140, n_pairs)]
+    dtw_a = [rng.standard_normal((order, n)) for n in la]          # (order, frames) as the reference holds them
+    dtw_b = [rng.standard_normal((order, n)) for n in lb]
+    src = [{"stft": (rng.standard_normal((n, 201)) + 1j * rng.standard_normal((n, 201))), "sp": rng.random((n, 513)) + 0.1}
+           for n in la]
+    tar = [{"stft": (rng.standard_normal((n, 201)) + 1j * rng.standard_normal((n, 201))), "sp": rng.random((n, 513)) + 0.1}
+           for n in lb]
+    # the reference's step-by-step route (host lists)
+    paths, _, _ = make_dict.dtw_alignment(dtw_a, dtw_b)
+    W_A, W_B = make_dict.make_exemplar_dict_W(paths)
+    want_A = np.concatenate([np.abs(np.asarray(f["stft"])[ia].real) for f, ia in zip(src, W_A)], axis=0)
+    want_B = np.concatenate([np.abs(np.asarray(f["stft"])[ib].real) for f, ib in zip(tar, W_B)], axis=0)
+    A, B, rows = evc.dtw_dictionary([a.T for a in dtw_a], [b.T for b in dtw_b], [f["stft"] for f in src],
+                                    [f["stft"] for f in tar], op="abs", real_part=True)
+    assert rows[-1] == len(want_A) and list(np.diff(rows)) == [len(p[0]) for p in paths]
+    assert np.array_equal(A.cpu().numpy(), want_A) and np.array_equal(B.cpu().numpy(), want_B)
+    # a WORLD stream (real frames, plain copy)
+    A2, B2, _ = evc.dtw_dictionary([a.T for a in dtw_a], [b.T for b in dtw_b], [f["sp"] for f in src], [f["sp"] for f in tar])
+    assert np.array_equal(A2.cpu().numpy(), np.concatenate([f["sp"][ia] for f, ia in zip(src, W_A)], axis=0))
+    assert np.array_equal(B2.cpu().numpy(), np.concatenate([f["sp"][ib] for f, ib in zip(tar, W_B)], axis=0))
+    # the prepared dictionary drives the solver like the host-built arrays do
+    pd, rows2 = make_dict.aligned_dictionary(dtw_a, dtw_b, src, tar, use_stft=True)
+    assert np.array_equal(rows, rows2)
+    X = np.abs(rng.standard_normal((50, 201)))
+    kw = dict(layout="frame_major", iters=12, eps_mode="zero_replace", init="sklearn")
+    H1, Y1 = evc.convert(pd, X, **kw)
+    H2, Y2 = evc.convert(want_A, X, want_B, **kw)
+    assert np.array_equal(H1, H2) and np.array_equal(Y1, Y2)

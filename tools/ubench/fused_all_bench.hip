@@ -74,7 +74,7 @@ int main(int argc, char** argv) {
     std::vector<int> fu(T, 0); int one = 1;
     double *dA1, *dA2, *dX, *dH, *dV, *dbuf; int *dfu, *dact, *dcnt; long long* ddbg;
     CK(hipMalloc(&dA1, A1p.size() * 8)); CK(hipMalloc(&dA2, A2p.size() * 8)); CK(hipMalloc(&dX, Xp.size() * 8));
-    CK(hipMalloc(&dH, Hp.size() * 8)); CK(hipMalloc(&dV, Vp.size() * 8)); CK(hipMalloc(&dbuf, (size_t)2 * ALL_MAX_WGS * 512 * 8));
+    CK(hipMalloc(&dH, Hp.size() * 8)); CK(hipMalloc(&dV, Vp.size() * 8)); CK(hipMalloc(&dbuf, (size_t)(ALL_SLICE_OFFSET + ALL_SLICE_ELEMS) * 8));
     CK(hipMalloc(&dfu, T * 4)); CK(hipMalloc(&dact, 4)); CK(hipMalloc(&dcnt, 1024 * 4));
     const size_t ndbg = (size_t)cus * 2 * (2 * iters + 1) * 4;
     CK(hipMalloc(&ddbg, ndbg * 8)); CK(hipMemset(ddbg, 0, ndbg * 8)); CK(hipMemset(dcnt, 0, 1024 * 4));
