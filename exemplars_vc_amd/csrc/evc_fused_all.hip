@@ -108,31 +108,38 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
     // hoisted out of the loops as per-lane 64-bit addresses (32 VGPRs).
     long sw = 0;
 
+    // Round 4: the fragments come by buffer loads - the tile's byte offset rides in the instruction's scalar offset, the
+    // lane's in a 32-bit register computed once, the k-step's in the immediate: no address arithmetic in the sweep.
+    // (As global loads the lane term became a 64-bit shift-and-add per fragment group: 6 vector instructions per unit,
+    // ~24 cycles beside the MFMAs; the compiler does not select the scalar-base form of global_load for it.)
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(A1p), 0, NT * (MSP * 512), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(A2p), 0, NT * (MT * 2048), 0x00020000);
+    const unsigned ul16 = ul * 16u, ul8 = ul * 8u;
     auto load_a1 = [&](double (&a1)[MSTEPS], int k) {
-        const f64x2* t = reinterpret_cast<const f64x2*>(A1p + (tile0 + sw + AW * k) * (MSP * 64));
+        const int so = (int)(tile0 + sw + AW * k) * (MSP * 512);
 #pragma unroll
         for (int s = 0; s < MSTEPS; s += 2) {
-            // (uniform part of the index on the pointer, the lane last: scalar base + 32-bit lane offset + immediate)
             if (s + 1 < MSTEPS) {
-                const f64x2 v = (t + (s >> 1) * 64)[ul];
+                const f64x2 v = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(r1, ul16 + (s >> 1) * 1024, so, 0));
                 a1[s] = v[0];
                 a1[s + 1] = v[1];
-            } else {
-                a1[s] = reinterpret_cast<const double*>(&(t + (s >> 1) * 64)[ul])[0];
+            } else {        // (the odd k-step's half of the pair: the first double of the lane's 16 bytes)
+                a1[s] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r1, ul16 + (s >> 1) * 1024, so, 0));
             }
         }
     };
     auto load_a2 = [&](double (&a2)[MT][4], int k) {
-        const f64x2* t = reinterpret_cast<const f64x2*>(A2p + (tile0 + sw + AW * k) * (MT * 256));
+        const int so = (int)(tile0 + sw + AW * k) * (MT * 2048);
 #pragma unroll
         for (int u = 0; u < MT; ++u)
 #pragma unroll
             for (int r = 0; r < 4; r += 2) {
-                const f64x2 v = (t + (u * 2 + (r >> 1)) * 64)[ul];
+                const f64x2 v = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(r2, ul16 + (u * 2 + (r >> 1)) * 1024, so, 0));
                 a2[u][r] = v[0];
                 a2[u][r + 1] = v[1];
             }
     };
+    (void)ul8;
 
     const int mode = a.eps_mode;
     const double eps = a.eps;
@@ -260,7 +267,7 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) h[k][r] *= d[r];
                     } else {
-                        mu_tile<false>(h[k], p[k], d, mode, eps, lo);
+                        mu_tile_guarded(h[k], p[k], d, mode, eps, lo);
                     }
 #pragma unroll
                     for (int u = 0; u < MT; ++u)

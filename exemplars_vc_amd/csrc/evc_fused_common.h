@@ -153,6 +153,34 @@ __device__ __forceinline__ void mu_tile(HT& h, const f64x4& p, const f64x4& dacc
     }
 }
 
+// mu_tile for the guarded modes only (k_fused_all, k_fused_xy never run EVC_EPS_NONE: no test of the mode in front of
+// every tile - a scalar branch and two mask moves per unit), divide-first, and with the exact path taken one quotient at
+// a time: it is the rare path (zero / denormal /
+// huge denominators, tiles holding padding exemplars under sklearn's guard), and four interleaved IEEE divisions need ~40
+// registers at the one point of the sweep where everything else is live too - enough to push activation tiles into
+// scratch memory for the whole loop.
+template <class HT>
+__device__ __forceinline__ void mu_tile_guarded(HT& h, const f64x4& p, const f64x4& dacc, int mode, double eps, unsigned lo) {
+    const unsigned span = FAST_HI_WORD > lo ? FAST_HI_WORD - lo : 0u;
+    const unsigned worst = max(max(hi_word(dacc[0]) - lo, hi_word(dacc[1]) - lo),
+                               max(hi_word(dacc[2]) - lo, hi_word(dacc[3]) - lo));
+    if (__builtin_expect(__all(worst < span), 1)) {
+        double rc[4];
+        batch_rcp(dacc, rc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = h[r] * (p[r] * rc[r]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double dn = dacc[r];
+            dn = (mode == EVC_EPS_ZERO_REPLACE && dn == 0.0) ? eps : dn;   // sklearn _nmf.py:620
+            dn = (mode == EVC_EPS_CLAMP && !(dn > eps)) ? eps : dn;         // deComP
+            h[r] = h[r] * (p[r] / dn);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // The same update split for software pipelining (k_fused_all): the quotients q = p / guard(d) of a tile.
 // mu_quot_fast is branch-free - it belongs to the basic block of the MFMAs it is interleaved with - and
 // returns whether every denominator of the lane allowed the fast path (its q is meaningless otherwise);

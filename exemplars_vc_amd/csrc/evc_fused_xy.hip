@@ -52,32 +52,6 @@ constexpr unsigned XY_POLL_LIMIT = 1u << 17;
 #define XY_STAMP(i)
 #endif
 
-// mu_tile (evc_fused_common.h) with the exact path taken one quotient at a time: it is the rare path (zero / denormal /
-// huge denominators, tiles holding padding exemplars under sklearn's guard), and four interleaved IEEE divisions need ~40
-// registers at the one point of the sweep where everything else is live too - enough to push activation tiles into
-// scratch memory for the whole loop.
-template <class HT>
-__device__ __forceinline__ void xy_update(HT& h, const f64x4& p, const f64x4& dacc, int mode, double eps, unsigned lo) {
-    const unsigned span = FAST_HI_WORD > lo ? FAST_HI_WORD - lo : 0u;
-    const unsigned worst = max(max(hi_word(dacc[0]) - lo, hi_word(dacc[1]) - lo),
-                               max(hi_word(dacc[2]) - lo, hi_word(dacc[3]) - lo));
-    if (__builtin_expect(__all(worst < span), 1)) {
-        double rc[4];
-        batch_rcp(dacc, rc);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = h[r] * (p[r] * rc[r]);
-    } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            double dn = dacc[r];
-            dn = (mode == EVC_EPS_ZERO_REPLACE && dn == 0.0) ? eps : dn;   // sklearn _nmf.py:620
-            dn = (mode == EVC_EPS_CLAMP && !(dn > eps)) ? eps : dn;         // deComP
-            h[r] = h[r] * (p[r] / dn);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
-
 // x + (x of lane ^ o) for o = 1, 2, 4, 8 as DPP moves (quad_perm, row_half_mirror, row_mirror: once the quads / halves of
 // a row hold one value each, the mirrors exchange exactly the partner's), else through the permute network.  Every
 // lane of a 2o-lane group ends with the same value: floating-point addition is commutative.
@@ -324,7 +298,7 @@ __global__ __launch_bounds__(XTHREADS, 2) void k_fused_xy(FusedArgs a) {
             for (int s = 0; s < MSTEPS; ++s) d = Mma<double>::mma(a1[s], v[s], d);
             load_a1(a1, (K + 1) % XKT);          // the next unit's (or the next sweep's first) fragments
             __builtin_amdgcn_sched_barrier(0);
-            xy_update(h[C][K], pk, d, mode, eps, lo);
+            mu_tile_guarded(h[C][K], pk, d, mode, eps, lo);
 #pragma unroll
             for (int u = 0; u < MT; ++u)
 #pragma unroll
