@@ -55,6 +55,9 @@ constexpr int AKT = 8;                 // exemplar tiles per wavefront, all regi
 constexpr int ATILES = AW * AKT;       // exemplar tiles per member
 constexpr int ATHREADS = 2 * AW * 64;  // two halves per workgroup
 constexpr unsigned ALL_POLL_LIMIT = 1u << 17;
+#ifndef EVC_ALL_EXCH_PRIO
+#define EVC_ALL_EXCH_PRIO 3
+#endif
 #ifndef EVC_ALL_C1_ALTERNATE
 #define EVC_ALL_C1_ALTERNATE 0
 #endif
@@ -285,6 +288,13 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
                 // for word; a thread beyond NE used to poll a word of the summed slices that nobody writes)
                 const int e0 = C <= 0 ? th % NE : th, e1 = th + AW * 64;
                 const bool has1 = e1 < NE;
+                // Round 4: the exchange is a chain of a few dozen dependent instructions (LDS, stores, polls) on a SIMD
+                // whose other wavefront issues MFMAs and vector work back to back; at equal priority the older wavefront
+                // wins the issue arbitration, so half 1's exchange (wavefronts 4-7) took 12.8 k cycles where half 0's
+                // took 10.4 k (profiles/r04_fused_all_stamps_prio_and_11_tiles.txt).  The exchanging wavefront goes
+                // first while it exchanges: its instructions are few, the sweep beside it does not notice.  Both
+                // exchanges then take 10.9 k and a C2 step 11.8 k cycles instead of 12.6 k.
+                __builtin_amdgcn_s_setprio(EVC_ALL_EXCH_PRIO);
                 double s0 = 0.0, s1 = 0.0;
 #pragma unroll
                 for (int ww = 0; ww < AW; ++ww) {
@@ -501,6 +511,7 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
                     rL[e0] = xL[e0] / (s0 < a.eps ? a.eps : s0);
                     if (has1) rL[e1] = xL[e1] / (s1 < a.eps ? a.eps : s1);
                 }
+                __builtin_amdgcn_s_setprio(0);
             }
             EVC_STAMP(1);
             __syncthreads();

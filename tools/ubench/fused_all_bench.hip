@@ -87,7 +87,7 @@ int main(int argc, char** argv) {
     a.frame_utt = dfu; a.active = dact; a.NT = NT; a.TT = TT; a.N = N; a.T_ = T; a.iters = iters; a.first = 0;
     a.write_err = 0; a.skip_all_live = 0; a.force_live = 0; a.exact_div = 0; a.loss = EVC_LOSS_FROBENIUS;
     a.eps_mode = EVC_EPS_ZERO_REPLACE; a.eps = 1.1920929e-7; a.l1 = 0.0;
-    a.coop_c = C; a.coop_buf = dbuf; a.coop_cnt = dcnt; a.coop_abort = dcnt + 512; a.groups = 0; a.dbg = ddbg;
+    a.M = M; a.spare_q = -1; a.coop_c = C; a.coop_buf = dbuf; a.coop_cnt = dcnt; a.coop_abort = dcnt + 512; a.groups = 0; a.dbg = ddbg;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e30f;
     for (int rep = 0; rep < 4; ++rep) {
