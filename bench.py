@@ -244,20 +244,34 @@ def cpu_baseline(M, N, K, l1, dtype, seed, T):
     return out, (p, act, Y)
 
 
-def pmc_traffic(kernel_tag, M, N, K, T, dtype):
+def kernel_instance(kernel_tag, M, members, loss):
+    """The template instance the library's routing implies for what evc_solve_info reported (None: not derivable) - the
+    string rocprofv3 prints for the kernel, so that a committed PMC summary can be tied to the run."""
+    if kernel_tag == "k_fused_all":
+        msteps = (M + 3) // 4 if M <= 16 else 4 + (M - 16 + 3) // 4
+        c = members if members in (1, 2, 4) else (0 if members in (8, 16, 32, 64) else -1)
+        return f"k_fused_all<{msteps}, {c}, {'true' if loss == 'kl' else 'false'}>"
+    return None
+
+
+def pmc_traffic(kernel_tag, M, N, K, T, dtype, members=None, loss="frobenius"):
     """HBM bytes per launch of the dominant kernel from a committed rocprofv3 PMC summary of this very workload
-    (rocprofv3 cannot run inside the timed process); (None, reason) when no matching file is on record."""
+    (rocprofv3 cannot run inside the timed process); (None, reason, False) when no matching file is on record.  The third
+    value says whether the summary's kernel instance (template arguments included) is the one this run reports - a
+    summary of another instance or of an older build of the kernel is still shown, but flagged."""
     import glob
+    want = kernel_instance(kernel_tag, M, members, loss)
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json")), reverse=True):
         try:
             pm = json.load(open(path))
             wl = pm["workload"]
             if (wl["M"], wl["N"], wl["K"], wl["frames"], wl["dtype"]) == (M, N, K, T, dtype) and \
                     kernel_tag in pm.get("kernel", ""):
-                return pm["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+                match = (pm.get("kernel") == want) if want else (pm.get("members") in (None, members))
+                return pm["hbm_bytes_per_launch"], os.path.relpath(path, ROOT), bool(match)
         except Exception:
             continue
-    return None, "no PMC summary under profiles/ matches this workload and kernel"
+    return None, "no PMC summary under profiles/ matches this workload and kernel", False
 
 
 def main():
@@ -410,7 +424,7 @@ def main():
             "k_gemm2": "k_gemm2 x2 per iteration (V = H Am^T, then the update as epilogue of V At^T)",
             "k_gemm_nt": "k_gemm_nt x2 per iteration (V = H Am^T, then the update as epilogue of V At^T)",
         }.get(ktag, ktag) + f"; members per frame tile/group: {sinfo.get('members', 1)}"
-        traffic, traffic_src = pmc_traffic(ktag, M, N, K, T, dtype)
+        traffic, traffic_src, traffic_match = pmc_traffic(ktag, M, N, K, T, dtype, sinfo.get("members"), args.loss)
         res = {
             "metric": "spectral frames/sec converted (100 NMF iters, N=4096 dict)" if (N, K) == (4096, 100)
                       else f"spectral frames/sec converted ({K} NMF iters, N={N} dict)",
@@ -435,6 +449,7 @@ def main():
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_run_match": traffic_match,
                 "kernel": f"iteration loop ({ktag})",
                 "launch_ms": 1e3 * loop_s,
                 "algorithmic_flops_per_launch": fl_loop,

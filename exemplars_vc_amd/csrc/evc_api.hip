@@ -522,29 +522,39 @@ WideWs<T> carve_wide(void* base, const Dims& d, int n_slots, int n_cus, bool wit
     w.bytes = (c.off + 255) & ~size_t(255);
     return w;
 }
-// float32 (k_fused_wide): batches of fewer than ~300 frame tiles (about seven utterances) stay on the two-contraction
-// path: with so few frames the exemplar ranges of a frame group must be many (23 for one utterance) and the
-// dependency hops of the task queue (publish, reduce, gather: measured ~40 us per iteration) outweigh what the
-// fusion saves - 90 against 47 us per iteration for one utterance, 139 / 132 for four, 226 / 241 for eight,
-// 334 / 457 for sixteen (profiles/r03_wide_tuning.md).  The tuning bits (ranges, wavefronts) force the fused
-// kernel at any size.
-constexpr int WIDE_MIN_TILES = 300;
-// float64 (k_fused_wide64), measured at M = 513, N = 8192 (tools/tune_wide64.py, K = 60; fraction of the fp64 matrix peak,
-// fused against two contractions): 2 utterances 0.32 / 0.58, 4: 0.63 / 0.59 (bench.py at K = 200: 0.57), 6: 0.63 / 0.50,
-// 8: 0.66 / 0.62, 16: 0.67 / 0.62, 32: 0.67 / 0.68, 64: 0.67 / 0.72 - the fused kernel serves the batches in between
-constexpr int WIDE64_MIN_TILES = 240, WIDE64_MAX_TILES = 1000;
+// Routing between the fused task-queue kernels and the two contractions, from the measured table
+// profiles/r04_routing_table.md (tools/tune_routing.py: whole calls, K = 20 and K = 80, N in {512 .. 16384}, 1 .. 64
+// utterances of 688 frames; round 3 had measured one (M, N) point per kernel):
+//  * float32 (k_fused_wide, 32 < M <= 208): up to four utterances the exemplar ranges of a frame group must be many and
+//    the dependency hops of the task queue (publish, reduce, gather: ~40 us per iteration) outweigh what the fusion
+//    saves (0.25 against 0.43 of the peak at 4 utterances, M = 201, N = 4096); from six utterances (258 frame tiles)
+//    on the fused kernel wins at every N measured (0.49 / 0.39 at six), by less and less towards 64 utterances; narrow
+//    spectra (M = 64) fall behind the two contractions from ~32 utterances on (0.349 / 0.353 ... 0.354 / 0.379).
+//  * float64 (k_fused_wide64, 208 < M <= 528): wins from four utterances (172 frame tiles) on - M = 513: 0.615 / 0.563
+//    at N = 4096, 0.653 / 0.619 at 16384, 0.49 / 0.42 at 1024 - up to ~24 utterances for N >= 2048 (32: 0.672 / 0.680;
+//    64: 0.674 / 0.721) and up to ~32 for smaller dictionaries (N = 1024: 0.649 / 0.632 at 32, 0.650 / 0.700 at 64).
+//    At M = 257 (4 bin tiles per wavefront: fewer MFMAs per block against the same fixed work) the window closes
+//    earlier: N < 2048 like above, 2048 <= N < 8192 up to ~14 utterances, from N = 8192 on the two contractions win
+//    throughout (0.549 / 0.596 at six utterances, N = 16384).
+// The tuning bits (ranges, wavefronts / bin tiles) force the fused kernel at any size.
+constexpr int WIDE_MIN_TILES = 240;
+constexpr int WIDE64_MIN_TILES = 172;
 bool use_wide(int M, int N, int T_, int dtype, int algo, int loss, int reserved) {
     if (reserved & EVC_FLAG_NO_FUSED) return false;
     // the task queues hand partial sums from workgroup to workgroup inside a launch and the call reads one word back at
     // the end (a wait that ran out): exactly what EVC_FLAG_NO_EXCHANGE rules out
     if (reserved & EVC_FLAG_NO_EXCHANGE) return false;
     const bool forced = ((reserved >> 8) & 0xff) != 0 || ((reserved >> 16) & 0xf) != 0;
+    const int tiles = (T_ + 15) / 16;
     if (dtype == EVC_F64) {
-        const int tiles = (T_ + 15) / 16;
-        return wide64_supported(M, N, T_, dtype, algo, loss) && (forced || (tiles >= WIDE64_MIN_TILES && tiles <= WIDE64_MAX_TILES));
+        if (!wide64_supported(M, N, T_, dtype, algo, loss)) return false;
+        if (forced) return true;
+        const int hi = N < 2048 ? 1400 : (M >= 400 ? 1000 : (N < 8192 ? 600 : 0));
+        return tiles >= WIDE64_MIN_TILES && tiles <= hi;
     }
     if (!wide_supported(M, N, T_, dtype, algo)) return false;
-    return forced || (T_ + 15) / 16 >= WIDE_MIN_TILES;
+    if (forced) return true;
+    return tiles >= WIDE_MIN_TILES && !(M <= 96 && tiles >= 1300);
 }
 
 template <typename T>

@@ -426,12 +426,16 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
                             __hip_atomic_fetch_add(&s_hb[half], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                         while ((int)(__hip_atomic_load(&s_hb[half], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - hb) < 0)
                             __builtin_amdgcn_s_sleep(1);
-                        if (th < 4 * ES) {
-                            const int el = th >> 2, q = th & 3, per = CR >> 2;
+                        // (round 4: as many lanes per element as the half has - 4 at 8 members, 8 at 16, 16 at 32, 32 at
+                        // 64 - so that a lane sums at most two staged values before the butterfly; with 4 lanes a lane
+                        // walked CR / 4 dependent LDS reads: 8 at C5)
+                        int LL = 4;
+                        while (2 * LL <= CR && 2 * LL * ES <= AW * 64) LL *= 2;
+                        if (th < LL * ES) {
+                            const int el = th / LL, q = th & (LL - 1), per = CR / LL;
                             double v = 0.0;
                             for (int i = 0; i < per; ++i) v += stage[(q * per + i) * ES + el];
-                            v += __shfl_xor(v, 1, 64);
-                            v += __shfl_xor(v, 2, 64);
+                            for (int o = 1; o < LL; o <<= 1) v += __shfl_xor(v, o, 64);
                             if (q == 0)
                                 __hip_atomic_store(xb2 + member * ES + el, (__double_as_longlong(v) & ~1LL) | tag,
                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -161,24 +161,27 @@ __device__ __forceinline__ void mu_tile(HT& h, const f64x4& p, const f64x4& dacc
 // scratch memory for the whole loop.
 template <class HT>
 __device__ __forceinline__ void mu_tile_guarded(HT& h, const f64x4& p, const f64x4& dacc, int mode, double eps, unsigned lo) {
+    // the fast quotients are formed unconditionally (straight-line code behind the D chain); the wavefront overwrites
+    // them on the exact path when any lane's denominators are out of the fast range
     const unsigned span = FAST_HI_WORD > lo ? FAST_HI_WORD - lo : 0u;
     const unsigned worst = max(max(hi_word(dacc[0]) - lo, hi_word(dacc[1]) - lo),
                                max(hi_word(dacc[2]) - lo, hi_word(dacc[3]) - lo));
-    if (__builtin_expect(__all(worst < span), 1)) {
-        double rc[4];
-        batch_rcp(dacc, rc);
+    double rc[4], q[4];
+    batch_rcp(dacc, rc);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) h[r] = h[r] * (p[r] * rc[r]);
-    } else {
+    for (int r = 0; r < 4; ++r) q[r] = p[r] * rc[r];
+    if (__builtin_expect(!__all(worst < span), 0)) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             double dn = dacc[r];
             dn = (mode == EVC_EPS_ZERO_REPLACE && dn == 0.0) ? eps : dn;   // sklearn _nmf.py:620
             dn = (mode == EVC_EPS_CLAMP && !(dn > eps)) ? eps : dn;         // deComP
-            h[r] = h[r] * (p[r] / dn);
+            q[r] = p[r] / dn;
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[r] = h[r] * q[r];
 }
 
 // The same update split for software pipelining (k_fused_all): the quotients q = p / guard(d) of a tile.

@@ -378,7 +378,9 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
         // behind its fourth.  The read is asm with the wait as a second statement naming the registers: the same read
         // as a C++ load costs 8 cycles per MFMA (tools/ubench/mfma64_fill.hip against mfma64_ports.hip: 72.0 / 66.8
         // ticks).  Between the two statements the compiler must not touch the destination (it counts as written at
-        // once): tools/asm_audit.py checks the generated code for exactly that.  f0, the fragment of position pc,
+        // once): tools/asm_audit.py checks the generated code for exactly that - the code THIS container's hipcc
+        // (ROCm 7.2) generates; another compiler release needs the audit run again (tests/test_wide64_build.py runs
+        // it on every CPU test pass, on whatever hipcc builds the library).  f0, the fragment of position pc,
         // is carried from section to section and step to step.
         // vmcnt counts in order: with R - 2 younger loads issued, vmcnt <= R - 2 says position pc + 1 has landed; other
         // loads and stores in between only make the wait stricter.

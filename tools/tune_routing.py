@@ -38,19 +38,20 @@ def timed(Ad, Xd, K, offs, **kw):
 def main():
     K = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     only = sys.argv[2] if len(sys.argv) > 2 else ""
+    quick = len(sys.argv) > 3 and sys.argv[3] == "quick"      # fewer N and batch sizes (long K)
     rng = np.random.default_rng(7)
     for dt, Ms in (("f32", (64, 201)), ("f64", (257, 513))):
         if only and only != dt:
             continue
         npdt = np.float32 if dt == "f32" else np.float64
         for M in Ms:
-            for N in (512, 1024, 4096, 8192, 16384):
+            for N in ((1024, 4096, 16384) if quick else (512, 1024, 4096, 8192, 16384)):
                 A = rng.random((N, M)) + 1e-3
                 A /= np.linalg.norm(A, axis=1, keepdims=True)
                 Ad = torch.from_numpy(A.astype(npdt)).cuda()
                 Xall = (A[rng.integers(0, N, 688 * 64)] * rng.random((688 * 64, 1)) + 1e-6).astype(npdt)
                 Xd_all = torch.from_numpy(Xall).cuda()
-                for U in (1, 2, 4, 6, 8, 12, 16, 24, 32, 64):
+                for U in ((2, 4, 6, 8, 12, 16, 32, 64) if quick else (1, 2, 4, 6, 8, 12, 16, 24, 32, 64)):
                     T = 688 * U
                     if dt == "f64" and N * T * 8 > 6e9:       # H alone beyond 6 GB: skip the corner
                         continue
