@@ -62,6 +62,10 @@ PRESETS = {
                    label="C5 at WORLD width (M=513)"),
     "STFT": dict(bins=201, exemplars=4096, iters=150, utterances=16, frames=688, dtype="f32", l1=0.0,
                  label="the script's own default flow: |Re STFT| of a complex64 transform, float32, M=201"),
+    "STFT64": dict(bins=201, exemplars=4096, iters=150, utterances=16, frames=688, dtype="f64", l1=0.0,
+                   label="the same flow with float64 spectra (04_align_n_nmf.py:398 loads audio as np.double; whether its "
+                         "librosa returns complex64 or complex128 is unpinned): no fused kernel for float64 at 33..208 bins, "
+                         "the two contractions serve it"),
 }
 
 

@@ -426,16 +426,16 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
                             __hip_atomic_fetch_add(&s_hb[half], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                         while ((int)(__hip_atomic_load(&s_hb[half], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) - hb) < 0)
                             __builtin_amdgcn_s_sleep(1);
-                        // (round 4: as many lanes per element as the half has - 4 at 8 members, 8 at 16, 16 at 32, 32 at
-                        // 64 - so that a lane sums at most two staged values before the butterfly; with 4 lanes a lane
-                        // walked CR / 4 dependent LDS reads: 8 at C5)
-                        int LL = 4;
-                        while (2 * LL <= CR && 2 * LL * ES <= AW * 64) LL *= 2;
-                        if (th < LL * ES) {
-                            const int el = th / LL, q = th & (LL - 1), per = CR / LL;
+                        // (4 lanes per element, each walking CR / 4 staged values.  Round 4 tried as many lanes as the half
+                        // has - 16 per element at 32 members, a lane summing two values before a 4-step butterfly:
+                        // slower, 1.63 against 1.53 ms per 60 iterations at C5 - the butterfly's permutes cost more than
+                        // the LDS reads they replace)
+                        if (th < 4 * ES) {
+                            const int el = th >> 2, q = th & 3, per = CR >> 2;
                             double v = 0.0;
                             for (int i = 0; i < per; ++i) v += stage[(q * per + i) * ES + el];
-                            for (int o = 1; o < LL; o <<= 1) v += __shfl_xor(v, o, 64);
+                            v += __shfl_xor(v, 1, 64);
+                            v += __shfl_xor(v, 2, 64);
                             if (q == 0)
                                 __hip_atomic_store(xb2 + member * ES + el, (__double_as_longlong(v) & ~1LL) | tag,
                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -608,7 +608,11 @@ static hipError_t pick_c(const FusedArgs& a, int n_cus, hipStream_t s) {
         // 8 members: the direct exchange (every member fetches all 8 partials: 296 GB of fabric traffic per C2 launch)
         // and the reduce-scatter (37 GB) run equally fast - 953 vs 958 k frames/s at C2, 537 vs 538 k for one
         // utterance - so the leaner one serves.  (Below 7 members its 4 lanes per element do not cover a slice.)
+#ifdef EVC_ALL_DIRECT8   // diagnostic (tools/ubench): the direct all-to-all at 8 members (one hand-off, 8 x the fetched bytes)
+        case 8: return launch_all<MSTEPS, 8, KL>(a, n_cus, s);
+#else
         case 8:
+#endif
         case 16:
         case 32:
         case 64: return launch_all<MSTEPS, 0, KL>(a, n_cus, s);    // run-time members, reduce-scatter, whole slices

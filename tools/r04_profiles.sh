@@ -11,6 +11,7 @@ python3 bench.py --config STFT --utterances 64 --steps 3 --warmup 1 --no-cpu >> 
 python3 bench.py --config STFT --utterances 1 --steps 10 --warmup 3 --no-cpu >> $OUT/bench_all_configs.jsonl 2>> $OUT/bench.err
 python3 bench.py --config C2 --utterances 1 --steps 10 --warmup 3 --no-cpu >> $OUT/bench_all_configs.jsonl 2>> $OUT/bench.err
 python3 bench.py --config C3 --utterances 16 --steps 2 --warmup 1 --no-cpu >> $OUT/bench_all_configs.jsonl 2>> $OUT/bench.err
+python3 bench.py --config STFT64 --steps 3 --warmup 1 --no-cpu >> $OUT/bench_all_configs.jsonl 2>> $OUT/bench.err
 python3 bench.py --config C2 --pair-tiles --steps 5 --warmup 2 --no-cpu >> $OUT/bench_all_configs.jsonl 2>> $OUT/bench.err
 echo "bench lines done" >&2
 bash tools/prof_bench.sh $OUT/c2 k_fused_all 25 4096 100 176128 f64 --config C2 > $OUT/prof_c2.log 2>&1
