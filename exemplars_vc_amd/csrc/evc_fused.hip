@@ -523,7 +523,7 @@ hipError_t fused_iterate(const FusedLayout& f, const FusedBuffers& b, const UttS
     a.eps_mode = eps_mode; a.eps = eps; a.l1 = l1;
     a.coop_c = 1; a.coop_buf = nullptr; a.coop_cnt = nullptr; a.coop_abort = nullptr; a.groups = 0;
     a.init_const = 0; a.h0 = nullptr; a.rsum = nullptr; a.Hx = nullptr; a.ldhx = 0; a.hx_frame_major = 0;
-    a.M = f.M; a.spare_q = -1;
+    a.M = f.M; a.spare_q = -1; a.stagger_cycles = 0;
     const bool xy = c_req == 0 && b.xy_c >= 2 && b.coop_buf && b.coop_cnt &&
                     fused_xy_members(f.NT, N, eps_mode, exact_div, loss) == b.xy_c;
     const bool all_res = xy || (c_req == 0 && b.all_c >= 1 && b.coop_buf && b.coop_cnt &&
@@ -574,7 +574,7 @@ hipError_t fused_synthesize(const FusedLayout& fB, const double* B2p, const doub
     a.NT = fB.NT; a.TT = fB.TT; a.N = N; a.T_ = T_;
     a.iters = 0; a.first = 1; a.write_err = 0; a.skip_all_live = 0; a.force_live = 1; a.loss = EVC_LOSS_FROBENIUS; a.exact_div = 0;
     a.Hx = nullptr; a.ldhx = 0; a.hx_frame_major = 0;
-    a.init_const = 0; a.h0 = nullptr; a.rsum = nullptr; a.M = fB.M; a.spare_q = -1;
+    a.init_const = 0; a.h0 = nullptr; a.rsum = nullptr; a.M = fB.M; a.spare_q = -1; a.stagger_cycles = 0;
     a.coop_c = 1; a.coop_buf = nullptr; a.coop_cnt = nullptr; a.coop_abort = nullptr; a.groups = 0;
     a.eps_mode = EVC_EPS_ADD; a.eps = 0; a.l1 = 0;
     hipError_t e = dispatch_msteps<1>(fB.msteps, a, s);

@@ -55,6 +55,9 @@ constexpr int AKT = 8;                 // exemplar tiles per wavefront, all regi
 constexpr int ATILES = AW * AKT;       // exemplar tiles per member
 constexpr int ATHREADS = 2 * AW * 64;  // two halves per workgroup
 constexpr unsigned ALL_POLL_LIMIT = 1u << 17;
+#ifndef EVC_ALL_STAGGER_PER_ITER
+#define EVC_ALL_STAGGER_PER_ITER 11000     // shader cycles of one iteration of one half (two steps) / 2 ... half a tile's duration = iters x one step
+#endif
 #ifndef EVC_ALL_EXCH_PRIO
 #define EVC_ALL_EXCH_PRIO 3
 #endif
@@ -172,6 +175,17 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
     }
     if (tid == 0) s_fail = 0;
     if (tid < 2) s_hb[tid] = 0;
+
+    // Short launches (the stop rule's 10-iteration pieces of a long batch): every group reaches the end of a frame tile
+    // at the same moment, and the chip then does nothing but store and reload activations (2 x 66 MB per round at C2:
+    // 21 us against 100 us of iterations, profiles/r04_default_call.md).  Every second pair of groups starts half a
+    // tile's duration late, once per launch, so that only half of the CUs move activations at any time: the default
+    // call's rate went from 0.845 to 0.866 of the rate without stop tests (same box, A/B; four or eight phases: the same -
+    // a CU streams at ~25 GB/s however many others do, so what is left would have to overlap with the CU's own sweeps).
+    if (a.stagger_cycles > 0 && ((blockIdx.x / CR) & 1)) {
+        const long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < a.stagger_cycles) __builtin_amdgcn_s_sleep(32);
+    }
 
     for (long tt0 = g - half; tt0 < a.TT; tt0 += a.groups) {     // half 0's tile decides (it has the lower index)
         const long tt = tt0 + half;
@@ -585,6 +599,8 @@ static hipError_t launch_all(FusedArgs a, int n_cus, hipStream_t s) {
     if (pairs > want) pairs = want;
     if (pairs < 1) return hipErrorInvalidValue;
     a.groups = 2 * pairs;
+    // stagger (see the kernel): launches of few iterations over many rounds of frame tiles
+    a.stagger_cycles = (a.iters > 0 && a.iters <= 25 && a.TT >= 4L * a.groups && pairs >= 2) ? (long long)a.iters * EVC_ALL_STAGGER_PER_ITER : 0;
     if (C != 1) {
         // stale words must not carry the epoch bit of the first two exchanges (0): fill with ones
         e = hipMemsetAsync(a.coop_buf, 0xFF, sizeof(double) * 2 * (size_t)a.groups * cr * (C < 0 ? ALL_RS_STRIDE : 512), s);

@@ -56,6 +56,7 @@ struct FusedArgs {
     // k_fused_xy: bins of the dictionary (0: unknown) and the lane group of the last k-step that holds the spare bin M
     // in which the denominators' start value travels (-1: not used); see evc_fused_xy.hip
     int M, spare_q;
+    long long stagger_cycles;    // k_fused_all: every second pair of groups starts this many shader cycles late (0: off)
 #if defined(EVC_ALL_TIMING) || defined(EVC_XY_TIMING)
     long long* dbg;          // tools/ubench/fused_all_bench.hip: s_memtime stamps of the first round's steps
 #endif
