@@ -120,8 +120,14 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
     // ~24 cycles beside the MFMAs; the compiler does not select the scalar-base form of global_load for it.)
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(A1p), 0, NT * (MSP * 512), 0x00020000);
     const __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(A2p), 0, NT * (MT * 2048), 0x00020000);
+#ifdef EVC_ALL_NOFRAG
+    bool nofrag_go = false;
+#endif
     const unsigned ul16 = ul * 16u, ul8 = ul * 8u;
     auto load_a1 = [&](double (&a1)[MSTEPS], int k) {
+#ifdef EVC_ALL_NOFRAG    // diagnostic (tools/ubench): no fragment traffic after the numerator pass (wrong results, timing only)
+        if (nofrag_go) return;
+#endif
         const int so = (int)(tile0 + sw + AW * k) * (MSP * 512);
 #pragma unroll
         for (int s = 0; s < MSTEPS; s += 2) {
@@ -135,6 +141,9 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
         }
     };
     auto load_a2 = [&](double (&a2)[MT][4], int k) {
+#ifdef EVC_ALL_NOFRAG
+        if (nofrag_go) return;
+#endif
         const int so = (int)(tile0 + sw + AW * k) * (MT * 2048);
 #pragma unroll
         for (int u = 0; u < MT; ++u)
@@ -258,6 +267,9 @@ __global__ __launch_bounds__(ATHREADS, 2) void k_fused_all(FusedArgs a) {
 
         if (valid && KL) load_a1(a1, 0);         // (the numerator pass, which otherwise leaves them, is skipped)
         for (int step = 0; step <= 2 * a.iters; ++step) {
+#ifdef EVC_ALL_NOFRAG
+            nofrag_go = step > 2;
+#endif
             // this half's turn on the matrix pipes.  (One member per frame tile - N <= 512 - has no exchange to hide:
             // both halves then sweep in the same steps, two wavefronts per SIMD.)
             const bool mine = (C == 1 && !EVC_ALL_C1_ALTERNATE) ? (step & 1) == 0 : (step & 1) == half;
