@@ -519,6 +519,18 @@ WideWs<T> carve_wide(void* base, const Dims& d, int n_slots, int n_cus, bool wit
     w.u.h0 = c.take<double>(d.n_utt);
     w.u.trace = c.take<double>((size_t)d.n_utt * n_slots);
     w.u.n_slots = n_slots;
+    if constexpr (sizeof(T) == 4) {
+        // k_fused_wide, several stop checks per launch: up to 4 snapshots of the activations (5 checks per launch), as
+        // many as fit in 2 GiB (a 16-utterance STFT batch: 180 MB each)
+        const size_t one = w.caps.hw * sizeof(float);
+        int slots = one ? (int)(((size_t)2 << 30) / one) : 0;
+        slots = slots > 4 ? 4 : slots;
+        w.fb.snap_slots = slots;
+        w.fb.hs_stride = w.caps.hw;
+        w.fb.err_stride = d.Tp;
+        w.fb.Hs = slots ? c.take<float>((size_t)slots * w.caps.hw) : nullptr;
+        w.fb.err2s = slots ? c.take<double>((size_t)slots * d.Tp) : nullptr;
+    }
     w.bytes = (c.off + 255) & ~size_t(255);
     return w;
 }
@@ -618,13 +630,28 @@ int solve_wide(const T* A, int lda, const T* X, int ldx, T* H, int ldh, int M, i
     if (fake_at == 0) HIP_TRY(hipMemsetAsync(abort_w, 1, sizeof(int), s));
     int launch_no = 0;
     int next_it = 0;                 // first iteration not yet run (0 = the pass that forms P and V = A H0)
-    auto run_to = [&](int it_end) -> int {      // iterations [next_it, it_end)
+    auto run_to = [&](int it_end, int snap_every = 0, int snap_first = 0) -> int {      // iterations [next_it, it_end)
         if (it_end <= next_it) return 0;
-        HIP_TRY(wide_iterate(fl, w.fb, w.u, N, T_, next_it, it_end, mode, o.eps, o.l1, init_const, n_cus, s));
+        if constexpr (sizeof(T) == 4)
+            HIP_TRY(wide_iterate(fl, w.fb, w.u, N, T_, next_it, it_end, mode, o.eps, o.l1, init_const, n_cus, s, snap_every,
+                                 snap_first));
+        else
+            HIP_TRY(wide_iterate(fl, w.fb, w.u, N, T_, next_it, it_end, mode, o.eps, o.l1, init_const, n_cus, s));
         ++inf->launches;
         next_it = it_end;
         return 0;
     };
+    // k_fused_wide: up to 1 + snap_slots stop checks per launch.  A launch boundary costs the task queue about one task
+    // time (the tail of one launch and the head of the next do not overlap) plus the residual kernel: with a check every
+    // 10 iterations that was 28 % of the STFT flow's default call at 16 utterances (profiles/r03_default_call_wide.jsonl).
+    // The checks inside a launch are evaluated after it, in order; an utterance that stopped at one of them gets the
+    // snapshot of that check back (k_wide_restore) - results are those of one launch per check, bit for bit.
+    int checks_per_launch = 1;
+    if constexpr (sizeof(T) == 4)
+        if (o.check_every > 0 && !kl) checks_per_launch = 1 + w.fb.snap_slots;
+    // (measurements only - tools/diag_wide_snap.py: EVC_WIDE_CHECKS_PER_LAUNCH=1 gives one launch per check back)
+    static const int diag_cap = getenv("EVC_WIDE_CHECKS_PER_LAUNCH") ? atoi(getenv("EVC_WIDE_CHECKS_PER_LAUNCH")) : 0;
+    if (diag_cap > 0 && checks_per_launch > diag_cap) checks_per_launch = diag_cap;
     auto check = [&](int c) -> int {
         HIP_TRY(wide_err2(fl, w.fb, w.u, N, T_, next_it - 1, kl ? 1 : 0, o.eps, w.err2, s));
         HIP_TRY(utt_check(w.err2, w.u, n_utt, c, o.check_every, o.stop_rule, o.tol, s));
@@ -641,11 +668,29 @@ int solve_wide(const T* A, int lda, const T* X, int ldx, T* H, int ldh, int M, i
     while (done < o.iters) {
         int n = o.iters - done;
         bool chk = false;
-        if (o.check_every > 0 && n >= o.check_every) { n = o.check_every; chk = true; }
+        int L = 1;
+        if (o.check_every > 0 && n >= o.check_every) {
+            // the checks of a launch are speculation: iterations behind a check at which every utterance stopped are
+            // thrown away.  The number grows with the iterations already done (1, 1, 2, 3, 4 ...: launches end at 10, 20,
+            // 40, 70, 110, 150 of the default call), so at most a third of a solve's iterations are wasted
+            L = 1 + done / (2 * o.check_every);
+            if (L > checks_per_launch) L = checks_per_launch;
+            if (L > n / o.check_every) L = n / o.check_every;
+            n = L * o.check_every;
+            chk = true;
+        }
         if (fake_at > 0 && launch_no == fake_at) HIP_TRY(hipMemsetAsync(abort_w, 1, sizeof(int), s));
         ++launch_no;
-        int st = run_to(done + n + 1);
+        int st = L > 1 ? run_to(done + n + 1, o.check_every, done + o.check_every) : run_to(done + n + 1);
         if (st) return st;
+        if constexpr (sizeof(T) == 4) {
+            for (int k = 0; k + 1 < L; ++k) {      // the checks inside the launch, oldest first
+                const int cno = done / o.check_every + 1 + k;
+                HIP_TRY(utt_check(w.fb.err2s + (size_t)k * w.fb.err_stride, w.u, n_utt, cno, o.check_every, o.stop_rule,
+                                  o.tol, s));
+                if (o.stop_rule != EVC_STOP_NONE) HIP_TRY(wide_restore(fl, w.fb, w.u, k, cno * o.check_every, T_, s));
+            }
+        }
         done += n;
         if (chk) {
             st = check(done / o.check_every);

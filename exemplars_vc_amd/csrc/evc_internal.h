@@ -234,6 +234,13 @@ struct WideLayout {
 struct WideBuffers {
     float *Aw, *Xw, *Hw, *Pw, *Vpart, *Vsum;
     unsigned* ctl;       // [4 + 2 G]: ticket, abort flag, -, -, done[G], done_r[G]
+    // several stop checks per launch (round 4): snapshots of the activations at the checks inside a launch and the
+    // residuals the following iteration's tasks leave (NULL / 0: one check per launch)
+    float* Hs;           // [snap_slots][hs_stride]
+    size_t hs_stride;
+    double* err2s;       // [snap_slots][err_stride]
+    long err_stride;
+    int snap_slots;
 };
 bool wide_supported(int M, int N, int T_, int dtype, int algo);
 // c_req / w_req: 0 = automatic (tuning and tests: ranges per group, wavefronts per workgroup)
@@ -251,8 +258,13 @@ hipError_t wide_import_h(const WideLayout& f, float* Hw, const float* H, long ld
 hipError_t wide_export_h(const WideLayout& f, const float* Hw, float* H, long ldh, int frame_major, int T_, int N,
                          const int* abort, hipStream_t s);
 hipError_t wide_begin(const WideLayout& f, const WideBuffers& b, hipStream_t s);
+// snap_every > 0: the iterations snap_first, snap_first + snap_every, ... < it_end - 1 are stop checks inside the launch
+// (b.Hs / b.err2s receive the activations and the residuals of check k in slot k; wide_restore puts a slot back)
 hipError_t wide_iterate(const WideLayout& f, const WideBuffers& b, const UttState& u, int N, int T_, int it_begin,
-                        int it_end, int mode, double eps, double l1, int init_const, int n_cus, hipStream_t s);
+                        int it_end, int mode, double eps, double l1, int init_const, int n_cus, hipStream_t s,
+                        int snap_every = 0, int snap_first = 0);
+hipError_t wide_restore(const WideLayout& f, const WideBuffers& b, const UttState& u, int slot, int target_iter, int T_,
+                        hipStream_t s);
 hipError_t wide_err2(const WideLayout& f, const WideBuffers& b, const UttState& u, int N, int T_, int it, int kl,
                      double eps, double* err2, hipStream_t s);
 

@@ -63,6 +63,17 @@ struct WideArgs {
     int mode;                // EVC_EPS_* or WIDE_KL
     float eps, l1;
     int init_const;          // 1: iteration 0 fills H with the utterances' constants (else Hw holds the given H0)
+    // Several stop checks per launch (round 4): the iterations snap_first, snap_first + snap_every, ... below
+    // it_end - 1 are CHECK iterations inside the launch.  Their H' is stored twice - in place and into snapshot slot k -
+    // and the sweep tasks of the following iteration, which sum the published V' anyway, leave the frames' squared
+    // residuals in err2s[k].  The host evaluates the stop rules of those checks after the launch, in order, and copies
+    // a snapshot back over the activations of an utterance that stopped there (it was iterated on to the end of the
+    // launch).  snap_every == 0: off.
+    int snap_every, snap_first;
+    float* Hs;               // [slots][hs_stride]
+    size_t hs_stride;
+    double* err2s;           // [slots][err_stride]
+    long err_stride;
 };
 
 __device__ __forceinline__ f32x4 ld_sc1(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {
@@ -120,9 +131,14 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
     const unsigned total = per_it * (unsigned)(a.it_end - a.it_begin);
     const unsigned c = (unsigned)a.c;
 
+    // The first ticket of a workgroup is its index (the counter starts at the grid size, wide_iterate): with first tickets
+    // drawn from the counter, the workgroups that arrived first had drawn their SECOND ticket (requested at the top of a
+    // task) before the last ones arrived, those started on tasks of the launch's second iteration and waited a whole task
+    // for them, and a launch that starts in the middle of a solve did not recover from that in 30 iterations (19 % of
+    // its time in dependency waits, tools/ubench/wide_bench.hip split mode, profiles/r04_wide_split_launch.md).
     unsigned nxt = 0;
     if (tid == 0) {
-        nxt = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        nxt = blockIdx.x;
         s_ctl[0] = nxt;
         s_ctl[1] = 1u;
     }
@@ -218,6 +234,14 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
         // ---- sweep task (iteration it, frame group g, exemplar range e) ----
         const int j0 = (int)((long)e * a.NB / a.c), j1 = (int)((long)(e + 1) * a.NB / a.c), nb = j1 - j0;
         const int ft = g * W + w;
+        // check iterations inside the launch (see WideArgs): this iteration's H' also goes to snapshot slot snap_slot; the
+        // V this task reads is the one a check iteration published: the range-0 task writes the residuals of slot err_slot
+        int snap_slot = -1, err_slot = -1;
+        if (a.snap_every > 0) {
+            const int d0 = it - a.snap_first, d1 = d0 - 1;
+            if (d0 >= 0 && it < a.it_end - 1 && d0 % a.snap_every == 0) snap_slot = d0 / a.snap_every;
+            if (e == 0 && d1 >= 0 && it - 1 < a.it_end - 1 && d1 % a.snap_every == 0) err_slot = d1 / a.snap_every;
+        }
         const bool on = ft < a.TT;                                // (wave-uniform) this wavefront has frames
         const bool kl = a.mode == WIDE_KL;
         if (nb > 0) stage_block(j0, 0);       // (the dictionary does not depend on anybody: its first block is on its way
@@ -283,6 +307,22 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
                     }
                 }
             }
+            if (err_slot >= 0) {      // ||x_t - v_t||^2 of this wavefront's 16 frames, summed as k_wide_err2 sums it
+                double acc = 0.0;
+#pragma unroll
+                for (int u = 0; u < MT; ++u) {
+                    const f32x4 x = xt[u * 64];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double xd = x[r], vd = Vin[u][r];
+                        acc += (xd - vd) * (xd - vd);
+                    }
+                }
+                acc += __shfl_xor(acc, 16, 64);
+                acc += __shfl_xor(acc, 32, 64);
+                const long t = 16L * ft + (lane & 15);
+                if (lane < 16 && t < a.T_) a.err2s[(long)err_slot * a.err_stride + t] = acc;
+            }
             if (kl && it > 0) {       // B operand of the KL numerator: X (/) max(V, eps)   (sklearn _nmf.py:560-575)
 #pragma unroll
                 for (int u = 0; u < MT; ++u) {
@@ -302,6 +342,8 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
         }
         const __amdgpu_buffer_rsrc_t rh = make_rsrc(a.Hw + (size_t)(on ? ft : 0) * a.NB * 256, (unsigned)a.NB * 1024u);
         const __amdgpu_buffer_rsrc_t rp = make_rsrc(a.Pw + (size_t)(on ? ft : 0) * a.NB * 256, (unsigned)a.NB * 1024u);
+        const __amdgpu_buffer_rsrc_t rhs = make_rsrc(
+            (snap_slot >= 0 ? a.Hs + (size_t)snap_slot * a.hs_stride : a.Hw) + (size_t)(on ? ft : 0) * a.NB * 256, (unsigned)a.NB * 1024u);
         const bool load_h = it > 0 || !a.init_const, load_p = it > 0 && !kl;
         // start value of the denominator's accumulator: l1, and pymf's + eps (ADD); iteration 0 forms the bare P
         const float c0 = it == 0 ? 0.f : a.l1 + (a.mode == EVC_EPS_ADD ? a.eps : 0.f);
@@ -450,7 +492,10 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
             const int jb = j0 + i, stn = st == NSTAGE - 1 ? 0 : st + 1;
             const char* sb = smem + (no_dma ? 0 : st) * IMG;
             const char* s2 = sb + MT * 1024;
-            if (on && have_s && !no_mem) st_sc1(rh, ((jb - 1) * 64 + lane) * 16u, hS);
+            if (on && have_s && !no_mem) {
+                st_sc1(rh, ((jb - 1) * 64 + lane) * 16u, hS);
+                if (snap_slot >= 0) st_sc1(rhs, ((jb - 1) * 64 + lane) * 16u, hS);
+            }
             if (i + 1 < nb) {
                 if (!no_dma) stage_block(jb + 1, stn);
                 if (on && !no_mem) {
@@ -487,7 +532,10 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
         WSTAMP(3);
         // publish the partial V' of this range (and the last block's activations)
         if (on) {
-            if (have_s) st_sc1(rh, ((j1 - 1) * 64 + lane) * 16u, hS);
+            if (have_s) {
+                st_sc1(rh, ((j1 - 1) * 64 + lane) * 16u, hS);
+                if (snap_slot >= 0) st_sc1(rhs, ((j1 - 1) * 64 + lane) * 16u, hS);
+            }
             const __amdgpu_buffer_rsrc_t rv =
                 make_rsrc(a.Vpart + (((size_t)(par * a.G + g) * c + e) * W + w) * (TILE_B / 4), TILE_B);
 #pragma unroll
@@ -612,6 +660,21 @@ __global__ __launch_bounds__(256) void k_wide_err2(WideArgs a, int MT, int W, in
     acc += __shfl_xor(acc, 32, 64);
     const long t = 16 * ft + (lane & 15);
     if (lane < 16 && t < a.T_) err2[t] = kl ? 2.0 * acc : acc;
+}
+
+// Hw <- Hs for the frames of utterances that stopped at the check whose iteration count is `target` (k_utt_check has just
+// set active = 0 and n_iter = target): they were iterated on to the end of the launch, the snapshot holds what the
+// reference holds.  One thread per 16 bytes of the activations.
+__global__ __launch_bounds__(256) void k_wide_restore(f32x4* __restrict__ Hw, const f32x4* __restrict__ Hs,
+                                                      const int* __restrict__ frame_utt, const int* __restrict__ active,
+                                                      const int* __restrict__ n_iter, int target, int NB, long tiles, int T_) {
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= tiles * NB * 64) return;
+    const long ft = gid / ((long)NB * 64);
+    const long t = 16 * ft + (gid & 15);
+    if (t >= T_) return;
+    const int ut = frame_utt[t];
+    if (ut >= 0 && active[ut] == 0 && n_iter[ut] == target) Hw[gid] = Hs[gid];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -751,17 +814,33 @@ static hipError_t wide_dispatch(int MT, const WideArgs& a, unsigned grid, hipStr
 
 // iterations [it_begin, it_end) in one launch (iteration 0: P = A^T X and V = A H0); one workgroup per CU
 hipError_t wide_iterate(const WideLayout& f, const WideBuffers& b, const UttState& u, int N, int T_, int it_begin,
-                        int it_end, int mode, double eps, double l1, int init_const, int n_cus, hipStream_t s) {
+                        int it_end, int mode, double eps, double l1, int init_const, int n_cus, hipStream_t s,
+                        int snap_every, int snap_first) {
     if (it_end <= it_begin) return hipSuccess;
     WideArgs a = wide_args(f, b, u, N, T_, mode, eps, l1, init_const);
     a.it_begin = it_begin; a.it_end = it_end;
-    hipError_t e = hipMemsetAsync(b.ctl, 0, sizeof(unsigned), s);       // the ticket counter of this launch
-    if (e != hipSuccess) return e;
+    a.snap_every = (snap_every > 0 && b.Hs && b.err2s) ? snap_every : 0;
+    a.snap_first = snap_first;
+    a.Hs = b.Hs; a.hs_stride = b.hs_stride; a.err2s = b.err2s; a.err_stride = b.err_stride;
+    if (a.snap_every > 0 && (it_end - 2 - snap_first) / a.snap_every >= b.snap_slots) return hipErrorInvalidValue;
     const long per_it = (long)f.G * f.c * (f.rmode ? 2 : 1);
     const long tasks = per_it * (it_end - it_begin);
     if (n_cus <= 0) n_cus = 256;
     const unsigned grid = (unsigned)(tasks < n_cus ? tasks : n_cus);
+    // the ticket counter of this launch: tickets 0 .. grid-1 belong to the workgroups by index
+    hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b.ctl), (int)grid, 1, s);
+    if (e != hipSuccess) return e;
     return f.W == 8 ? wide_dispatch<8>(f.MT, a, grid, s) : wide_dispatch<4>(f.MT, a, grid, s);
+}
+
+hipError_t wide_restore(const WideLayout& f, const WideBuffers& b, const UttState& u, int slot, int target_iter, int T_,
+                        hipStream_t s) {
+    if (!b.Hs || slot < 0 || slot >= b.snap_slots) return hipErrorInvalidValue;
+    const long tiles = (long)f.G * f.W, n = tiles * f.NB * 64;
+    hipLaunchKernelGGL(k_wide_restore, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, reinterpret_cast<f32x4*>(b.Hw),
+                       reinterpret_cast<const f32x4*>(b.Hs + (size_t)slot * b.hs_stride), u.frame_utt, u.active, u.n_iter,
+                       target_iter, f.NB, tiles, T_);
+    return hipGetLastError();
 }
 
 // per-frame residuals of the activations after iteration `it` (the V' that iteration published)

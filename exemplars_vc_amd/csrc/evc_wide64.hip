@@ -154,9 +154,10 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
     const unsigned ring_s = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)ring_w);
     const unsigned hp_s = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)&s_hp[w][0][0]);
 
+    // (the first ticket is the workgroup's index and the counter starts at the grid size: see k_fused_wide)
     unsigned nxt = 0;
     if (tid == 0) {
-        nxt = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        nxt = blockIdx.x;
         s_ctl[0] = nxt;
         s_ctl[1] = 1u;
     }
@@ -851,12 +852,12 @@ hipError_t wide_iterate(const Wide64Layout& f, const Wide64Buffers& b, const Utt
     // (mode: EVC_EPS_*, + 0x1000 when the caller wants correctly rounded quotients)
     Wide64Args a = wide64_args(f, b, u, N, T_, mode & 0xfff, eps, l1, init_const, (mode >> 12) & 1);
     a.it_begin = it_begin; a.it_end = it_end;
-    hipError_t e = hipMemsetAsync(b.ctl, 0, sizeof(unsigned), s);
-    if (e != hipSuccess) return e;
     const long per_it = (long)f.G * f.c * (f.rmode ? 2 : 1);
     const long tasks = per_it * (it_end - it_begin);
     if (n_cus <= 0) n_cus = 256;
     const unsigned grid = (unsigned)(tasks < n_cus ? tasks : n_cus);
+    hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b.ctl), (int)grid, 1, s);
+    if (e != hipSuccess) return e;
     switch (f.TPW) {
         case 4: return wide64_launch<4>(a, grid, s);
         case 5: return wide64_launch<5>(a, grid, s);

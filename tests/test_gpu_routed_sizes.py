@@ -157,19 +157,20 @@ def test_a_voided_task_queue_solve_is_redone_and_says_so(dtype, M, kernel, redo_
     """A bounded wait of the task-queue kernels that runs out raises a flag (evc_wide.hip / evc_wide64.hip).  Round 3
     exported NaN under status 0; now the flag is read back before anything reaches H or Y and the solve is redone on the
     two contractions (evc_solve_info.redo = 1).  The test raises the flag as a timed-out wait would
-    (evc_solve_opts.test_abort_at): at the start of the call, and in front of the second launch of a checked solve."""
+    (evc_solve_opts.test_abort_at): at the start of the call, and in front of a later launch of a checked solve."""
     import exemplars_vc_amd as evc
     o = oracle()
     p = o.synth_problem(M, 384, 150, seed=3)
     A, X, B = p["A"].astype(dtype), p["X"].astype(dtype), p["B"].astype(dtype)
     H0 = (np.random.default_rng(1).random((384, 150)) + 1e-4).astype(dtype)
-    kw = dict(iters=12, eps_mode="add", eps=1e-9, fused_w=4, check_every=4, info=True)
+    # (60 iterations, a check every 4: three launches on either kernel - k_fused_wide takes up to five checks per launch)
+    kw = dict(iters=60, eps_mode="add", eps=1e-9, fused_w=4, check_every=4, info=True)
     Hc, Yc, ic = evc.convert(A, X, B, H0.copy(), **kw)
     assert ic["kernel"] == kernel and ic["redo"] == 0, ic
     Hr, Yr, ir = evc.convert(A, X, B, H0.copy(), _fake_coop_timeout=when, **kw)
     assert ir["redo"] == 1 and ir["kernel"] == redo_kernel, ir
     assert np.isfinite(Hr).all() and np.isfinite(Yr).all()
-    want = o.mu_solve(A.astype(np.float64), X.astype(np.float64), H0.astype(np.float64), 12, eps_mode=o.EPS_ADD, eps=1e-9,
+    want = o.mu_solve(A.astype(np.float64), X.astype(np.float64), H0.astype(np.float64), 60, eps_mode=o.EPS_ADD, eps=1e-9,
                       algo="factored")
     tol = dict(rtol=1e-8, atol=0) if dtype == np.float64 else dict(rtol=2e-3, atol=1e-6 * float(want.max()))
     np.testing.assert_allclose(Hr, want, **tol)

@@ -1,7 +1,9 @@
 // Stand-alone timing harness for k_fused_wide (diagnostic build with per-task real-time stamps).
 // Build (from the repo root):
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DEVC_WIDE_STAMP -o tools/ubench/bin/wide_bench tools/ubench/wide_bench.hip
-// Run on the GPU box: tools/ubench/bin/wide_bench [utterances=1] [c=0] [W=0] [K=150] [M=201] [N=4096]
+// Run on the GPU box: tools/ubench/bin/wide_bench [utterances=1] [c=0] [W=0] [K=150] [M=201] [N=4096] [split=0]
+// split > 0: iteration 0 in a launch of its own, then launches of `split` iterations (what the stop checks of a call do);
+// a per-iteration table follows (start of the first task, mean wait / blocks / publish of the sweep tasks).
 // Prints the launch time and, per task kind, the mean length in microseconds of each phase:
 //   sweep : wait (dependency) | load (V in, first block staged) | blocks | publish (+ drain + barrier) | tail
 //   reduce: wait | sum (loads issued, stores issued) | drain | tail
@@ -24,6 +26,7 @@ __global__ void k_fill_utt(int* frame_utt, int* active, double* h0, int Tp, int 
 int main(int argc, char** argv) {
     const int U = argc > 1 ? atoi(argv[1]) : 1, c_req = argc > 2 ? atoi(argv[2]) : 0, w_req = argc > 3 ? atoi(argv[3]) : 0;
     const int K = argc > 4 ? atoi(argv[4]) : 150, M = argc > 5 ? atoi(argv[5]) : 201, N = argc > 6 ? atoi(argv[6]) : 4096;
+    const int split = argc > 7 ? atoi(argv[7]) : 0;
     const int T = 688 * U, Mk = round_up(M, 16), Np = round_up(N, 128), Tp = round_up(T, 64);
     int dev = 0, cus = 0;
     CK(hipGetDevice(&dev));
@@ -72,7 +75,18 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 4; ++rep) {
         CK(wide_begin(f, b, 0));
         CK(hipEventRecord(e0, 0));
-        CK(wide_iterate(f, b, u, N, T, 0, K + 1, EVC_EPS_ZERO_REPLACE, 1.1920929e-7, 0.0, 1, cus, 0));
+        if (split <= 0) {
+            CK(wide_iterate(f, b, u, N, T, 0, K + 1, EVC_EPS_ZERO_REPLACE, 1.1920929e-7, 0.0, 1, cus, 0));
+        } else {
+            // (the stamps are indexed by the ticket of a launch: each launch gets its own part of the buffer)
+            for (int it = 0; it < K + 1;) {
+                const int n = it == 0 ? 1 : (K + 1 - it < split ? K + 1 - it : split);
+                unsigned long long* part = dbg + (size_t)per_it * it * 8;
+                CK(hipMemcpyToSymbolAsync(HIP_SYMBOL(evc_wide_dbg), &part, sizeof(part), 0, hipMemcpyHostToDevice, 0));
+                CK(wide_iterate(f, b, u, N, T, it, it + n, EVC_EPS_ZERO_REPLACE, 1.1920929e-7, 0.0, 1, cus, 0));
+                it += n;
+            }
+        }
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
@@ -102,5 +116,26 @@ int main(int argc, char** argv) {
     unsigned long long lo = ~0ULL, hi = 0;
     for (long t = per_it * itm; t < per_it * (itm + 1); ++t) { if (h[t * 8] && h[t * 8] < lo) lo = h[t * 8]; if (h[t * 8 + 5] > hi) hi = h[t * 8 + 5]; }
     printf("iteration %ld spans %.2f us (first task start to last task end)\n", itm, (hi - lo) / 100.0);
+    if (argc > 8) {
+        unsigned long long t0 = ~0ULL;
+        for (long t = 0; t < per_it; ++t) if (h[t * 8] && h[t * 8] < t0) t0 = h[t * 8];
+        printf("it | first start us | last end us | sweep: wait load blocks publish | max blocks | reduce: wait\n");
+        for (long it = 0; it <= K; ++it) {
+            unsigned long long a0 = ~0ULL, a1 = 0;
+            double sw[4] = {0, 0, 0, 0}, rw = 0, mb = 0; long ns = 0, nr = 0;
+            for (long t = per_it * it; t < per_it * (it + 1); ++t) {
+                const unsigned long long* x = &h[(size_t)t * 8];
+                if (!x[0] || !x[5]) continue;
+                if (x[0] < a0) a0 = x[0];
+                if (x[5] > a1) a1 = x[5];
+                const unsigned long long x1 = x[1] ? x[1] : x[0];
+                if ((x[6] & 1) == 0) { ++ns; sw[0] += x1 - x[0]; sw[1] += x[2] - x1; sw[2] += x[3] - x[2]; sw[3] += x[4] - x[3]; if (x[3] - x[2] > mb) mb = x[3] - x[2]; }
+                else { ++nr; rw += x1 - x[0]; }
+            }
+            if (!ns) continue;
+            printf("%3ld %9.1f %9.1f | %7.1f %6.1f %7.1f %6.1f | %7.1f | %7.1f\n", it, (a0 - t0) / 100.0, (a1 - t0) / 100.0, sw[0] / ns / 100,
+                   sw[1] / ns / 100, sw[2] / ns / 100, sw[3] / ns / 100, mb / 100, nr ? rw / nr / 100 : 0.0);
+        }
+    }
     return 0;
 }
