@@ -64,8 +64,8 @@ PRESETS = {
                  label="the script's own default flow: |Re STFT| of a complex64 transform, float32, M=201"),
     "STFT64": dict(bins=201, exemplars=4096, iters=150, utterances=16, frames=688, dtype="f64", l1=0.0,
                    label="the same flow with float64 spectra (04_align_n_nmf.py:398 loads audio as np.double; whether its "
-                         "librosa returns complex64 or complex128 is unpinned): no fused kernel for float64 at 33..208 bins, "
-                         "the two contractions serve it"),
+                         "librosa returns complex64 or complex128 is unpinned): k_fused_wide64 with 3 whole bin tiles per "
+                         "wavefront + the split one (round 4; rounds 1-3: the two contractions)"),
 }
 
 
@@ -423,7 +423,7 @@ def main():
             "k_fused_mu": "k_fused_mu (persistent fused update, activations streamed)",
             "k_fused_wide": "k_fused_wide (fused FACTORED for M > 32: task queue over frame groups x exemplar ranges, "
                             "dictionary blocks shared through LDS, V resident per wavefront, H and P streamed once)",
-            "k_fused_wide64": "k_fused_wide64 (fused FACTORED for float64, 208 < M <= 528: the same task queue; a workgroup's "
+            "k_fused_wide64": "k_fused_wide64 (fused FACTORED for float64, 144 < M <= 528: the same task queue; a workgroup's "
                               "four wavefronts split the bins of 32 frames, fragments through per-wavefront LDS rings)",
             "k_gemm2": "k_gemm2 x2 per iteration (V = H Am^T, then the update as epilogue of V At^T)",
             "k_gemm_nt": "k_gemm_nt x2 per iteration (V = H Am^T, then the update as epilogue of V At^T)",

@@ -55,7 +55,7 @@ struct DictPlan {
     bool fused;          // float64 fused kernels (M <= 32): operand fragments, row sums
     bool packed_b;       // ... and B's fragments for the synthesis from packed tiles (1 <= Mb <= 32)
     bool wide;           // k_fused_wide's block images (float32, 32 < M <= 208)
-    bool wide64;         // k_fused_wide64's block images (float64, 208 < M <= 528, Frobenius)
+    bool wide64;         // k_fused_wide64's block images (float64, 144 < M <= 528, Frobenius)
     bool kl;             // the dictionary divided by its column sums
     bool bc;             // a compact exemplars-as-rows copy of B (prepared images: the caller's B is not consulted)
 };
@@ -542,7 +542,7 @@ WideWs<T> carve_wide(void* base, const Dims& d, int n_slots, int n_cus, bool wit
 //    saves (0.25 against 0.43 of the peak at 4 utterances, M = 201, N = 4096); from six utterances (258 frame tiles)
 //    on the fused kernel wins at every N measured (0.49 / 0.39 at six), by less and less towards 64 utterances; narrow
 //    spectra (M = 64) fall behind the two contractions from ~32 utterances on (0.349 / 0.353 ... 0.354 / 0.379).
-//  * float64 (k_fused_wide64, 208 < M <= 528): wins from four utterances (172 frame tiles) on - M = 513: 0.615 / 0.563
+//  * float64 (k_fused_wide64, 144 < M <= 528; 208 < M here, M <= 208 below): wins from four utterances (172 frame tiles) on - M = 513: 0.615 / 0.563
 //    at N = 4096, 0.653 / 0.619 at 16384, 0.49 / 0.42 at 1024 - up to ~24 utterances for N >= 2048 (32: 0.672 / 0.680;
 //    64: 0.674 / 0.721) and up to ~32 for smaller dictionaries (N = 1024: 0.649 / 0.632 at 32, 0.650 / 0.700 at 64).
 //    At M = 257 (4 bin tiles per wavefront: fewer MFMAs per block against the same fixed work) the window closes
@@ -561,6 +561,15 @@ bool use_wide(int M, int N, int T_, int dtype, int algo, int loss, int reserved)
     if (dtype == EVC_F64) {
         if (!wide64_supported(M, N, T_, dtype, algo, loss)) return false;
         if (forced) return true;
+        if (M <= 208) {
+            // 3 whole bin tiles per wavefront + the split one (round 4; profiles/r04_routing_table.md, f64 M = 201 / 160):
+            // 0.52 of the peak from six utterances on where the two contractions give 0.39 - 0.49 (STFT flow in float64,
+            // 16 utterances: 83.3 k against 74.4 k frames/s); from ~48 utterances on they win again (0.58 at 64), and
+            // with fewer than 12 of the 13 tile slots used (M <= 176: 0.42 at M = 160) throughout
+            if (M <= 176) return false;
+            const int lo = N < 2048 ? WIDE64_MIN_TILES : (N < 8192 ? 240 : 500);
+            return tiles >= lo && tiles <= 2000;
+        }
         const int hi = N < 2048 ? 1400 : (M >= 400 ? 1000 : (N < 8192 ? 600 : 0));
         return tiles >= WIDE64_MIN_TILES && tiles <= hi;
     }
@@ -1132,7 +1141,7 @@ static int solve_checked(const void* A, int lda, const void* X, int ldx, void* H
     {   // tuning bits 16..19: wavefronts per workgroup of k_fused_wide (4 | 8), whole bin tiles per wavefront of
         // k_fused_wide64 (4 | 5 | 7 | 8: the narrowest instance >= the request that holds M); anything else is an error
         const int tw = (o.reserved >> 16) & 0xf;
-        if (M > 32 && tw != 0 && !(o.dtype == EVC_F32 ? (tw == 4 || tw == 8) : (tw == 4 || tw == 5 || tw == 7 || tw == 8)))
+        if (M > 32 && tw != 0 && !(o.dtype == EVC_F32 ? (tw == 4 || tw == 8) : (tw == 3 || tw == 4 || tw == 5 || tw == 7 || tw == 8)))
             return ST_BADARG;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -269,7 +269,7 @@ hipError_t wide_err2(const WideLayout& f, const WideBuffers& b, const UttState& 
                      double eps, double* err2, hipStream_t s);
 
 // ----- evc_wide64.hip -----
-// The same task queue for wide float64 spectra (208 < M <= 528, Frobenius): k_fused_wide64; a workgroup of four
+// The same task queue for wide float64 spectra (144 < M <= 528, Frobenius): k_fused_wide64; a workgroup of four
 // wavefronts owns 32 frames, the bins are split over its wavefronts.
 struct Wide64Layout {
     int TPW;             // whole bin tiles of 16 per wavefront (template instance: 64 TPW + 16 >= M; the last tile is split)

@@ -1,5 +1,6 @@
-// k_fused_wide64: the fused FACTORED multiplicative update for wide float64 spectra (208 < M <= 528 bins: the
-// 513-bin STFT magnitudes of BASELINE C3 / C5_513; 04_align_n_nmf.py:315-326 with fft_size 1024).
+// k_fused_wide64: the fused FACTORED multiplicative update for wide float64 spectra (144 < M <= 528 bins: the
+// 513-bin STFT magnitudes of BASELINE C3 / C5_513, 04_align_n_nmf.py:315-326 with fft_size 1024; the 201-bin
+// |Re STFT| flow when its spectra are float64, 04_align_n_nmf.py:398,422 - 3 whole bin tiles per wavefront + the split one).
 //
 //   per iteration and frame:  D = A^T V (+ l1, + eps)      V = A H of the previous iteration
 //                             H' = H (.) P (/) guard(D)     P = A^T X, formed once
@@ -130,7 +131,8 @@ __device__ __forceinline__ void w64_settle() { asm volatile("s_nop 15\n\ts_nop 3
 template <int TPW>
 __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
     constexpr int NL = 2 * TPW;                       // 16-byte fragment loads per product and wavefront
-    constexpr int KH = (TPW + 1) / 2;                 // bin tiles of the V' product that run before the first barrier
+    constexpr int KH = TPW == 3 ? 1 : (TPW + 1) / 2;  // bin tiles of the V' product that run before the first barrier (the second
+                                                      // half keeps >= 3 fragment positions for the update's three pieces)
     constexpr int TS = TPW + 1;                       // tile slots per frame tile in a wavefront's V chunk (the last: the extra tile)
     constexpr int CP = 2 * NL + 1;                    // fragment positions per block (chunk)
     constexpr unsigned WCH = 2u * TS * 2048u;         // bytes of a wavefront's V chunk (2 frame tiles x TS slots x 2 KiB)
@@ -734,12 +736,12 @@ __global__ __launch_bounds__(256) void k_wide64_err2(Wide64Args a, int TPW, int 
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-static const int WIDE64_TPW_SET[] = {4, 5, 7, 8};      // whole bin tiles per wavefront; + one tile split over the four
+static const int WIDE64_TPW_SET[] = {3, 4, 5, 7, 8};      // whole bin tiles per wavefront; + one tile split over the four
 
 size_t wide_ctl_words(const Wide64Layout& f) { return 4 + 2 * (size_t)f.G; }
 
 bool wide64_supported(int M, int N, int T_, int dtype, int algo, int loss) {
-    return dtype == EVC_F64 && algo == EVC_ALGO_FACTORED && loss == EVC_LOSS_FROBENIUS && M > 208 && M <= 528 &&
+    return dtype == EVC_F64 && algo == EVC_ALGO_FACTORED && loss == EVC_LOSS_FROBENIUS && M > 144 && M <= 528 &&
            N >= 16 && T_ >= 1;
 }
 
@@ -859,6 +861,7 @@ hipError_t wide_iterate(const Wide64Layout& f, const Wide64Buffers& b, const Utt
     hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b.ctl), (int)grid, 1, s);
     if (e != hipSuccess) return e;
     switch (f.TPW) {
+        case 3: return wide64_launch<3>(a, grid, s);
         case 4: return wide64_launch<4>(a, grid, s);
         case 5: return wide64_launch<5>(a, grid, s);
         case 7: return wide64_launch<7>(a, grid, s);

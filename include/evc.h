@@ -36,7 +36,7 @@
  *         the solve is redone without any exchange).  EVC_FLAG_NO_EXCHANGE keeps such a call fully
  *         asynchronous (at about half the speed for a lone utterance, ~10 % less for large batches);
  *     (3) evc_nmf_solve / evc_nmf_convert on the task-queue kernels for wide spectra (k_fused_wide: float32,
- *         32 < M <= 208, batches from ~7 utterances on; k_fused_wide64: float64, 208 < M <= 528, 6 .. ~20 utterances):
+ *         32 < M <= 208, batches from ~7 utterances on; k_fused_wide64: float64, 176 < M <= 528, 6 .. ~20 utterances):
  *         the same round trip, taken BEFORE anything is written to H or Y, so that a solve whose wait ran out is
  *         redone on the two-contraction path from the untouched inputs (evc_solve_info.redo = 1).  Round 3 delivered
  *         NaN under status 0 there.  EVC_FLAG_NO_EXCHANGE routes away from these kernels too.
@@ -136,7 +136,7 @@ typedef struct evc_solve_opts {
     int reserved;      /* flags, 0 = defaults: an OR of EVC_FLAG_* (below); bits 8..15: tuning only - M <= 32: 1 | 2 force
                           the general streamed kernel with that many frame tiles per workgroup; M > 32: that many exemplar
                           ranges per frame group in k_fused_wide / k_fused_wide64, whatever the batch size; bits 16..19,
-                          tuning only: k_fused_wide with 4 | 8 wavefronts per workgroup, k_fused_wide64 with at least 4 | 5 | 7 | 8
+                          tuning only: k_fused_wide with 4 | 8 wavefronts per workgroup, k_fused_wide64 with at least 3 | 4 | 5 | 7 | 8
                           whole bin tiles per wavefront (the narrowest instance that holds M); other values: status -1; with
                           a prepared dictionary whose images do not fit the override: status -3 */
     int loss;          /* EVC_LOSS_* */
@@ -173,7 +173,7 @@ enum {
     EVC_KERNEL_FUSED_RES = 4,   /* k_fused_res: half of H register-resident (members > 1: its cooperative launch) */
     EVC_KERNEL_FUSED_ALL = 5,   /* k_fused_all: H and P register-resident, `members` workgroups per frame tile */
     EVC_KERNEL_FUSED_WIDE = 6,  /* k_fused_wide: fused FACTORED for float32, 32 < M <= 208: task queue over (frame group, exemplar range) */
-    EVC_KERNEL_FUSED_WIDE64 = 7, /* k_fused_wide64: the same for float64, 208 < M <= 528 (bins split over a workgroup's wavefronts) */
+    EVC_KERNEL_FUSED_WIDE64 = 7, /* k_fused_wide64: the same for float64, 144 < M <= 528 (bins split over a workgroup's wavefronts) */
     EVC_KERNEL_FUSED_XY = 8     /* k_fused_xy: H and P register-resident, `members` workgroups per PAIR of frame tiles, the
                                    exchange phases inside the sweeps (round 4; on request only: EVC_FLAG_PAIR_TILES) */
 };

@@ -129,7 +129,8 @@ def test_stft_flow_batch_of_16_on_the_fused_float32_kernel():
 def test_real_audio_golden_replicated_16_times_through_the_batch_entry(tag):
     """tests/golden/audio_stft_n4096_*: the reference's audio, scikit-learn's own output (140 iterations at tol 1e-4).
     Sixteen copies through compat.factorize_utterances (one launch sequence): every copy stops where scikit-learn
-    stopped and synthesises scikit-learn's Y; the fused float32 kernel serves the float32 batch."""
+    stopped and synthesises scikit-learn's Y; the fused float32 kernel serves the float32 batch, k_fused_wide64 (3 whole
+    bin tiles per wavefront + the split one, round 4) the float64 batch - at 1e-8 of scikit-learn's output."""
     from exemplars_vc_amd.compat.factorize import factorize_utterances, synthesize_rows
     g32 = load_golden(GOLDEN + "/audio_stft_n4096_f32.npz")
     g = g32 if tag == "f32" else load_golden(GOLDEN + "/audio_stft_n4096_f64.npz")
@@ -138,7 +139,7 @@ def test_real_audio_golden_replicated_16_times_through_the_batch_entry(tag):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         Hs, n_iter, info = factorize_utterances([X] * 16, A, tol=float(g["tol"]), return_info=True)
-    assert info["kernel"] == ("k_fused_wide" if tag == "f32" else "k_gemm_nt"), info
+    assert info["kernel"] == ("k_fused_wide" if tag == "f32" else "k_fused_wide64"), info
     assert [int(n) for n in n_iter] == [int(g["n_iter"])] * 16 == [140] * 16
     for u in (0, 5, 15):
         Y = synthesize_rows(Hs[u], B)

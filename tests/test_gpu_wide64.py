@@ -1,8 +1,8 @@
-"""k_fused_wide64 (evc_wide64.hip): the fused FACTORED update for wide float64 spectra (208 < M <= 528 bins; the
-513-bin STFT magnitudes of BASELINE C3 / C5_513).
+"""k_fused_wide64 (evc_wide64.hip): the fused FACTORED update for wide float64 spectra (144 < M <= 528 bins; the
+513-bin STFT magnitudes of BASELINE C3 / C5_513, and from round 4 the 201-bin |Re STFT| flow in float64).
 
 The library routes batches of 240 ... 1000 frame tiles to it (6 to ~20 utterances: DESIGN.md section 5.2b, where it
-beats the two-contraction path); elsewhere the tuning bits select it: `fused_w >= 4` (the narrowest instance of 4, 5,
+beats the two-contraction path); elsewhere the tuning bits select it: `fused_w >= 3` (the narrowest instance of 3, 4, 5,
 7 or 8 whole bin tiles per wavefront, plus one tile split over the four, that holds M) and / or `fused_c` (exemplar ranges per frame group).  Every case enters through the C ABI
 and is compared with the float64 oracle on the same inputs; tolerance 1e-9 relative (summation order only: the
 quotient is the correctly rounded division)."""
@@ -34,13 +34,15 @@ def sk_want(o, A, X, K, l1=0.0):
     (513, 1000, 100, 8, 0, 8), (513, 1000, 100, 8, 6, 8), (257, 300, 70, 10, 0, 4), (400, 512, 33, 10, 5, 7),
     (528, 200, 17, 10, 0, 8), (209, 128, 32, 10, 2, 4), (320, 512, 130, 8, 8, 5), (448, 130, 1, 8, 0, 7),
     (513, 17, 5, 6, 0, 8), (272, 256, 48, 8, 2, 4), (273, 256, 48, 8, 2, 5), (512, 256, 48, 8, 3, 8),
+    (201, 256, 64, 12, 0, 3), (201, 300, 50, 10, 2, 3), (145, 128, 40, 8, 1, 3), (208, 200, 33, 10, 3, 3), (201, 1000, 100, 8, 6, 3),
+    (193, 64, 1, 6, 0, 3),
 ])
 def test_wide64_kernel_against_the_oracle(M, N, T, K, c, tpw):
     import exemplars_vc_amd as evc
     o = oracle()
     p = o.synth_problem(M, N, T, seed=M + N + T)
     got, info = evc.solve_activations(p["A"], p["X"], iters=K, eps_mode="zero_replace", init="sklearn", fused_c=c,
-                                      fused_w=4, info=True)
+                                      fused_w=min(tpw, 4), info=True)
     assert info["kernel"] == "k_fused_wide64" and info["launches"] == 1 and info["redo"] == 0, info
     if c:
         assert info["members"] == min(c, max(1, ((N + 15) // 16) // 2)), info
@@ -54,6 +56,12 @@ def test_wide64_routing_by_batch_size():
     o = oracle()
     for T, kernel in ((64, "k_gemm_nt"), (4000, "k_fused_wide64")):
         p = o.synth_problem(513, 256, T, seed=T)
+        got, info = evc.solve_activations(p["A"], p["X"], iters=4, eps_mode="zero_replace", init="sklearn", info=True)
+        assert info["kernel"] == kernel, info
+        check(got, sk_want(o, p["A"], p["X"], 4))
+    # 3 whole bin tiles per wavefront (176 < M <= 208): from 240 frame tiles on at N >= 2048, from 172 below
+    for M, T, kernel in ((201, 4000, "k_fused_wide64"), (201, 1000, "k_gemm_nt"), (170, 4000, "k_gemm_nt")):
+        p = o.synth_problem(M, 256, T, seed=T + M)
         got, info = evc.solve_activations(p["A"], p["X"], iters=4, eps_mode="zero_replace", init="sklearn", info=True)
         assert info["kernel"] == kernel, info
         check(got, sk_want(o, p["A"], p["X"], 4))

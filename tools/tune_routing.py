@@ -3,7 +3,7 @@
 and k_fused_wide64 (float64, M = 257, 513) against k_gemm2 / k_gemm_nt over N in {512 ... 16384} and 1 ... 64 utterances
 of 688 frames.  GPU box:
 
-    python tools/tune_routing.py [K=20] > gpurun_out/r04/tune_routing.jsonl
+    python tools/tune_routing.py [K=20] [f32|f64] [quick] [M,M,...] > gpurun_out/r04/tune_routing.jsonl
 
 One JSON line per (dtype, M, N, utterances): milliseconds and fraction of the matrix peak of both routes, the faster one,
 and what the library's default routing picks."""
@@ -39,12 +39,13 @@ def main():
     K = int(sys.argv[1]) if len(sys.argv) > 1 else 20
     only = sys.argv[2] if len(sys.argv) > 2 else ""
     quick = len(sys.argv) > 3 and sys.argv[3] == "quick"      # fewer N and batch sizes (long K)
+    only_m = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else None      # e.g. 201 with only = f64
     rng = np.random.default_rng(7)
     for dt, Ms in (("f32", (64, 201)), ("f64", (257, 513))):
         if only and only != dt:
             continue
         npdt = np.float32 if dt == "f32" else np.float64
-        for M in Ms:
+        for M in (only_m or Ms):
             for N in ((1024, 4096, 16384) if quick else (512, 1024, 4096, 8192, 16384)):
                 A = rng.random((N, M)) + 1e-3
                 A /= np.linalg.norm(A, axis=1, keepdims=True)
@@ -58,7 +59,7 @@ def main():
                     offs = np.arange(U + 1, dtype=np.int32) * 688
                     Xd = Xd_all[:T]
                     tg, ig = timed(Ad, Xd, K, offs, fused=False)
-                    tf, if_ = timed(Ad, Xd, K, offs, fused_w=4)
+                    tf, if_ = timed(Ad, Xd, K, offs, fused_w=3 if (dt == "f64" and M <= 208) else 4)
                     _, idef = timed(Ad, Xd, 1, offs)
                     fl = K * (4.0 * M * N + 3.0 * N) * T
                     print(json.dumps({"dtype": dt, "M": M, "N": N, "utterances": U, "frame_tiles": (T + 15) // 16, "K": K,

@@ -1,4 +1,4 @@
-"""Quick parity sweep of k_fused_wide64 (float64, 208 < M <= 528) against the oracle: shapes, exemplar-range counts,
+"""Quick parity sweep of k_fused_wide64 (float64, 144 < M <= 528) against the oracle: shapes, exemplar-range counts,
 eps modes, given H0, stop rule, synthesis; then the C3 shape timed (one utterance and, with `--batch`, sixteen).
 Run on the GPU box:  python tools/wide64_check.py [--batch]"""
 import os
@@ -24,6 +24,7 @@ def main():
         (513, 256, 64, 20, 0), (513, 256, 64, 20, 1), (513, 256, 40, 20, 2), (513, 250, 50, 20, 3),
         (513, 1000, 100, 12, 0), (513, 1000, 100, 12, 6), (257, 300, 70, 15, 0), (400, 512, 33, 15, 5),
         (528, 200, 17, 15, 0), (209, 128, 32, 15, 2), (320, 512, 130, 10, 8),
+        (201, 256, 64, 20, 0), (201, 300, 50, 15, 2), (145, 128, 40, 10, 1), (208, 200, 33, 12, 3), (201, 1000, 100, 12, 6),
     ]
     for (M, N, T, K, c) in cases:
         p = o.synth_problem(M, N, T, seed=M + N + T)
@@ -31,7 +32,7 @@ def main():
         want = o.mu_solve(A, X, np.full((N, T), np.sqrt(X.mean() / N)), K, eps_mode=o.EPS_ZERO_REPLACE,
                           eps=float(np.finfo(np.float64).eps), algo="factored")
         t0 = time.time()
-        got, info = evc.solve_activations(A, X, iters=K, eps_mode="zero_replace", init="sklearn", fused_c=c, fused_w=4, info=True)
+        got, info = evc.solve_activations(A, X, iters=K, eps_mode="zero_replace", init="sklearn", fused_c=c, fused_w=3 if M <= 208 else 4, info=True)
         dt = time.time() - t0
         r = rel(got, want)
         ok = r < 1e-9 and info["kernel"] == "k_fused_wide64"
