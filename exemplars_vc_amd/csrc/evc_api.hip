@@ -535,21 +535,23 @@ WideWs<T> carve_wide(void* base, const Dims& d, int n_slots, int n_cus, bool wit
     return w;
 }
 // Routing between the fused task-queue kernels and the two contractions, from the measured table
-// profiles/r04_routing_table.md (tools/tune_routing.py: whole calls, K = 20 and K = 80, N in {512 .. 16384}, 1 .. 64
+// profiles/r04_routing_table.md (tools/tune_routing.py: whole calls, K = 20 and K = 80, N in {1024, 4096, 16384}, 1 .. 64
 // utterances of 688 frames; round 3 had measured one (M, N) point per kernel):
-//  * float32 (k_fused_wide, 32 < M <= 208): up to four utterances the exemplar ranges of a frame group must be many and
-//    the dependency hops of the task queue (publish, reduce, gather: ~40 us per iteration) outweigh what the fusion
-//    saves (0.25 against 0.43 of the peak at 4 utterances, M = 201, N = 4096); from six utterances (258 frame tiles)
-//    on the fused kernel wins at every N measured (0.49 / 0.39 at six), by less and less towards 64 utterances; narrow
-//    spectra (M = 64) fall behind the two contractions from ~32 utterances on (0.349 / 0.353 ... 0.354 / 0.379).
+//  * float32 (k_fused_wide, 32 < M <= 208), 8 wavefronts per workgroup and - up to ~5 utterances - the static schedule
+//    (profiles/r04_wide_small_batches.md): ahead of the two contractions from one utterance on at N = 16384 (M = 201:
+//    0.476 / 0.413 of the peak), from two (M = 201) or three (M = 64) at N = 4096 (0.384 / 0.338; 0.259 / 0.203), from six
+//    at N = 1024 (0.338 / 0.302), and by more and more towards 64 utterances (M = 201, N = 4096: 0.705 / 0.526; the first
+//    sweep of this round had forced FOUR wavefronts per workgroup at every size and found the opposite).  One utterance
+//    at N = 4096 stays with the two contractions (0.272 / 0.296: two hand-offs of ~11 us per iteration beside 22 us of
+//    block steps).
 //  * float64 (k_fused_wide64, 144 < M <= 528; 208 < M here, M <= 208 below): wins from four utterances (172 frame tiles) on - M = 513: 0.615 / 0.563
 //    at N = 4096, 0.653 / 0.619 at 16384, 0.49 / 0.42 at 1024 - up to ~24 utterances for N >= 2048 (32: 0.672 / 0.680;
 //    64: 0.674 / 0.721) and up to ~32 for smaller dictionaries (N = 1024: 0.649 / 0.632 at 32, 0.650 / 0.700 at 64).
 //    At M = 257 (4 bin tiles per wavefront: fewer MFMAs per block against the same fixed work) the window closes
 //    earlier: N < 2048 like above, 2048 <= N < 8192 up to ~14 utterances, from N = 8192 on the two contractions win
-//    throughout (0.549 / 0.596 at six utterances, N = 16384).
+//    throughout (0.549 / 0.596 at six utterances, N = 16384).  One and two utterances: the static schedule brought the
+//    fused kernel from 0.35 to 0.55 of the peak at the C3 shape, the two contractions give 0.60 / 0.65.
 // The tuning bits (ranges, wavefronts / bin tiles) force the fused kernel at any size.
-constexpr int WIDE_MIN_TILES = 240;
 constexpr int WIDE64_MIN_TILES = 172;
 bool use_wide(int M, int N, int T_, int dtype, int algo, int loss, int reserved) {
     if (reserved & EVC_FLAG_NO_FUSED) return false;
@@ -575,7 +577,8 @@ bool use_wide(int M, int N, int T_, int dtype, int algo, int loss, int reserved)
     }
     if (!wide_supported(M, N, T_, dtype, algo)) return false;
     if (forced) return true;
-    return tiles >= WIDE_MIN_TILES && !(M <= 96 && tiles >= 1300);
+    const int lo = N >= 8192 ? 43 : (N >= 2048 ? (M > 96 ? 86 : 129) : (M > 96 ? 240 : 300));
+    return tiles >= lo;
 }
 
 template <typename T>
@@ -658,9 +661,6 @@ int solve_wide(const T* A, int lda, const T* X, int ldx, T* H, int ldh, int M, i
     int checks_per_launch = 1;
     if constexpr (sizeof(T) == 4)
         if (o.check_every > 0 && !kl) checks_per_launch = 1 + w.fb.snap_slots;
-    // (measurements only - tools/diag_wide_snap.py: EVC_WIDE_CHECKS_PER_LAUNCH=1 gives one launch per check back)
-    static const int diag_cap = getenv("EVC_WIDE_CHECKS_PER_LAUNCH") ? atoi(getenv("EVC_WIDE_CHECKS_PER_LAUNCH")) : 0;
-    if (diag_cap > 0 && checks_per_launch > diag_cap) checks_per_launch = diag_cap;
     auto check = [&](int c) -> int {
         HIP_TRY(wide_err2(fl, w.fb, w.u, N, T_, next_it - 1, kl ? 1 : 0, o.eps, w.err2, s));
         HIP_TRY(utt_check(w.err2, w.u, n_utt, c, o.check_every, o.stop_rule, o.tol, s));

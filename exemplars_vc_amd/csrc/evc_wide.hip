@@ -36,6 +36,8 @@
 // wavefronts load behind a barrier that lane then joins.  One workgroup per CU.
 #include "evc_internal.h"
 
+#include <stdlib.h>
+
 namespace evc {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -70,6 +72,11 @@ struct WideArgs {
     // a snapshot back over the activations of an utterance that stopped there (it was iterated on to the end of the
     // launch).  snap_every == 0: off.
     int snap_every, snap_first;
+    // 1: no ticket counter - workgroup b runs sweep task b (and reduce slice b) of every iteration.  For batches whose
+    // sweep tasks of one iteration fit the CUs (G c <= CUs: up to ~5 utterances): with tickets drawn in order a workgroup
+    // that finished early drew a reduce task whose group was still sweeping and sat on it (1 utterance: 30 us of a
+    // reduce task's 36, 4 utterances: 97 of 106 - profiles/r04_wide_small_batches.md)
+    int static_q;
     float* Hs;               // [slots][hs_stride]
     size_t hs_stride;
     double* err2s;           // [slots][err_stride]
@@ -182,9 +189,13 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
         const unsigned tk = __builtin_amdgcn_readfirstlane(s_ctl[0]);
         if (tk >= total) break;
         __syncthreads();                       // everybody has read the ticket before thread 0 replaces it
-        if (tid == 0)                          // the next ticket is requested now and used at the end of this task
-            nxt = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned itl = tk / per_it, rem = tk - itl * per_it;
+        if (tid == 0) {                        // the next ticket is requested now and used at the end of this task
+            if (a.static_q)                    // (static: this workgroup's reduce slice, then its sweep of the next iteration)
+                nxt = (a.rmode && rem < GC) ? tk + GC : (itl + 1) * per_it + blockIdx.x;
+            else
+                nxt = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         const int it = a.it_begin + (int)itl;
         const bool reduce = rem >= GC;
         const unsigned idx = reduce ? rem - GC : rem;
@@ -202,6 +213,9 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
             const unsigned lo = (unsigned)((unsigned long)e * U / c), hi = (unsigned)((unsigned long)(e + 1) * U / c);
             const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.Vpart + ((size_t)(par * a.G + g) * c) * U * 4, c * U * 16u);
             const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.Vsum + (size_t)(par * a.G + g) * U * 4, U * 16u);
+            // (sharing a unit's c partials between thread sets - one batch of loads in flight instead of two - shortened the
+            // sum from 5.8 to 4.8 us at c = 42 and lengthened the wait in front of it by as much: the task ends when the
+            // slowest member's partial has arrived, not when this workgroup has added up; dropped)
             for (unsigned un = lo + tid; un < hi; un += W * 64) {
                 // 24 loads in flight at a time (each is a memory round trip), summed in range order
                 f32x4 acc = f32x4{0, 0, 0, 0};
@@ -697,9 +711,11 @@ WideLayout wide_layout(int M, int N, int T_, int n_cus, int c_req, int w_req) {
     f.NB = (N + 15) / 16;
     f.TT = (T_ + 15) / 16;
     if (n_cus <= 0) n_cus = 256;
-    // 8 wavefronts per workgroup (two per SIMD cover each other's latencies; half the dictionary traffic per flop)
-    // once there are frame tiles for it; 4 for a few utterances, where more, smaller groups keep the partial sums small
-    f.W = w_req == 4 || w_req == 8 ? w_req : (f.TT >= 2 * n_cus ? 8 : 4);
+    // 8 wavefronts per workgroup (two per SIMD cover each other's latencies; half the dictionary traffic per flop).
+    // Rounds 2-3 took 4 below 512 frame tiles (more, smaller groups); with the static schedule 8 wins at every batch
+    // size measured (1 / 2 / 4 / 8 utterances: 47.8 / 71.9 / 114.5 / 213.5 us per iteration against 55.5 / 81.8 / 148.0 /
+    // 230.9 - profiles/r04_wide_small_batches.md)
+    f.W = w_req == 4 || w_req == 8 ? w_req : 8;
     f.G = (f.TT + f.W - 1) / f.W;
     // ranges per frame group: enough tasks per iteration to keep every CU busy (none when the groups alone do)
     // (never more tasks per iteration than workgroups when the ranges are many: the surplus would wait a whole task)
@@ -826,7 +842,15 @@ hipError_t wide_iterate(const WideLayout& f, const WideBuffers& b, const UttStat
     const long per_it = (long)f.G * f.c * (f.rmode ? 2 : 1);
     const long tasks = per_it * (it_end - it_begin);
     if (n_cus <= 0) n_cus = 256;
-    const unsigned grid = (unsigned)(tasks < n_cus ? tasks : n_cus);
+#ifdef EVC_WIDE_STAMP      // (the stand-alone harnesses only: the library reads nothing from the environment)
+    static const int no_static = getenv("EVC_WIDE_NO_STATIC") ? atoi(getenv("EVC_WIDE_NO_STATIC")) : 0;
+#else
+    constexpr int no_static = 0;
+#endif
+    // (two 4-wavefront workgroups per CU, one sweeping while the other exchanges, were tried: 90 us per iteration at one
+    // utterance against 48 - twice the partial sums to exchange, and the two share the matrix pipe)
+    a.static_q = (f.G * f.c <= n_cus && !no_static) ? 1 : 0;
+    const unsigned grid = a.static_q ? (unsigned)(f.G * f.c) : (unsigned)(tasks < n_cus ? tasks : n_cus);
     // the ticket counter of this launch: tickets 0 .. grid-1 belong to the workgroups by index
     hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b.ctl), (int)grid, 1, s);
     if (e != hipSuccess) return e;

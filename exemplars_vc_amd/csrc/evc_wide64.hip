@@ -36,6 +36,7 @@
 //   matrix pipe.
 #include "evc_internal.h"
 
+#include <stdlib.h>
 #include <type_traits>
 
 namespace evc {
@@ -68,6 +69,7 @@ struct Wide64Args {
     double eps, l1;
     int init_const;
     int exact;               // 1: correctly rounded quotients (else one shared reciprocal per lane, <= 2 ulp)
+    int static_q;            // 1: workgroup b runs sweep task b and reduce slice b of every iteration (G c <= CUs)
 };
 
 __device__ __forceinline__ w64_d2 ld2_sc1(__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) {
@@ -192,8 +194,13 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
         const unsigned tk = __builtin_amdgcn_readfirstlane(s_ctl[0]);
         if (tk >= total) break;
         __syncthreads();
-        if (tid == 0) nxt = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned itl = tk / per_it, rem = tk - itl * per_it;
+        if (tid == 0) {
+            if (a.static_q)        // (no ticket counter: this workgroup's reduce slice, then its sweep of the next iteration - see k_fused_wide)
+                nxt = (a.rmode && rem < GC) ? tk + GC : (itl + 1) * per_it + blockIdx.x;
+            else
+                nxt = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         const int it = a.it_begin + (int)itl;
         const bool reduce = rem >= GC;
         const unsigned idx = reduce ? rem - GC : rem;
@@ -857,7 +864,13 @@ hipError_t wide_iterate(const Wide64Layout& f, const Wide64Buffers& b, const Utt
     const long per_it = (long)f.G * f.c * (f.rmode ? 2 : 1);
     const long tasks = per_it * (it_end - it_begin);
     if (n_cus <= 0) n_cus = 256;
-    const unsigned grid = (unsigned)(tasks < n_cus ? tasks : n_cus);
+#ifdef EVC_WIDE_STAMP      // (the stand-alone harnesses only: the library reads nothing from the environment)
+    static const int no_static = getenv("EVC_WIDE_NO_STATIC") ? atoi(getenv("EVC_WIDE_NO_STATIC")) : 0;
+#else
+    constexpr int no_static = 0;
+#endif
+    a.static_q = (f.G * f.c <= n_cus && !no_static) ? 1 : 0;
+    const unsigned grid = a.static_q ? (unsigned)(f.G * f.c) : (unsigned)(tasks < n_cus ? tasks : n_cus);
     hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b.ctl), (int)grid, 1, s);
     if (e != hipSuccess) return e;
     switch (f.TPW) {

@@ -36,7 +36,8 @@
  *         the solve is redone without any exchange).  EVC_FLAG_NO_EXCHANGE keeps such a call fully
  *         asynchronous (at about half the speed for a lone utterance, ~10 % less for large batches);
  *     (3) evc_nmf_solve / evc_nmf_convert on the task-queue kernels for wide spectra (k_fused_wide: float32,
- *         32 < M <= 208, batches from ~7 utterances on; k_fused_wide64: float64, 176 < M <= 528, 6 .. ~20 utterances):
+ *         32 < M <= 208, from one to six utterances on depending on the dictionary size; k_fused_wide64: float64,
+ *         176 < M <= 528, 4 .. ~30 utterances):
  *         the same round trip, taken BEFORE anything is written to H or Y, so that a solve whose wait ran out is
  *         redone on the two-contraction path from the untouched inputs (evc_solve_info.redo = 1).  Round 3 delivered
  *         NaN under status 0 there.  EVC_FLAG_NO_EXCHANGE routes away from these kernels too.

@@ -96,15 +96,17 @@ def test_c3_one_call_of_16384_frames():
     assert float((H[688:688 + 64] - H[:64]).abs().max() / H[:64].abs().max()) <= 1e-12
 
 
-def test_stft_flow_batch_of_16_on_the_fused_float32_kernel():
-    """M = 201, N = 4096, K = 150, float32, 16 x 688 frames -> k_fused_wide; 48 frames against the float64 oracle on the
+@pytest.mark.parametrize("U", [16, 2, 5])
+def test_stft_flow_batches_on_the_fused_float32_kernel(U):
+    """M = 201, N = 4096, K = 150, float32, U x 688 frames -> k_fused_wide (16: the task queue; 2 and 5: the static
+    schedule of round 4, one sweep task per workgroup); 48 frames against the float64 oracle on the
     same float32 inputs.  The drift of a float32 trajectory over 150 iterations of 4096-term sums is reported and bounded
     (north_star's 1e-4 is asked of the float64 path; scikit-learn's own float32 run differs from its float64 run by the
     same order, tests/golden/audio_stft_n4096_f32 vs _f64)."""
     import torch
     import exemplars_vc_amd as evc
     o = oracle()
-    M, N, K, T, U = 201, 4096, 150, 688, 16
+    M, N, K, T = 201, 4096, 150, 688
     p = o.synth_problem(M, N, T, seed=201)
     A, B, X, offs = _batch_of_copies(p, U, np.float32)
     dev = torch.device("cuda:0")
@@ -121,7 +123,7 @@ def test_stft_flow_batch_of_16_on_the_fused_float32_kernel():
     print(f"k_fused_wide at K=150 N=4096: max rel drift on entries > 1e-4 max: {drift_big:.2e}; max abs / max: {drift_abs:.2e}")
     assert drift_big <= 2e-3 and drift_abs <= 1e-4
     H0 = H[:T]
-    for u in (1, 8, 15):
+    for u in (1, U // 2, U - 1):
         assert float((H[u * T:(u + 1) * T] - H0).abs().max() / H0.abs().max()) <= 1e-5
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """k_fused_wide, STFT flow at 16 utterances, 150 iterations, residuals recorded every `check_every` iterations, no stop
-rule (every variant runs the same iterations): what launches and in-launch checks cost.  With
-EVC_WIDE_CHECKS_PER_LAUNCH=1 in the environment every check ends a launch.  GPU box: python tools/diag_wide_snap.py"""
+rule (every variant runs the same iterations): what launches and in-launch checks cost.  (The one-launch-per-check lines of profiles/r04_wide_split_launch.md came from a build with the checks per launch
+capped at 1.)  GPU box: python tools/diag_wide_snap.py"""
 import json, os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -21,4 +21,4 @@ for ce in (0, 50, 10, 30, 75):
         _, info = evc.solve_activations(A, X, layout="frame_major", iters=150, eps_mode="zero_replace", init="sklearn",
                                         utt_offsets=offs, out=H, check_every=ce, stop_rule="none", info=True, loop_events=(ev0, ev1))
         torch.cuda.synchronize()
-    print(json.dumps({"env": os.environ.get("EVC_WIDE_CHECKS_PER_LAUNCH"), "check_every": ce, "loop_ms": round(ev0.elapsed_time(ev1), 3), "launches": info["launches"]}), flush=True)
+    print(json.dumps({"check_every": ce, "loop_ms": round(ev0.elapsed_time(ev1), 3), "launches": info["launches"]}), flush=True)

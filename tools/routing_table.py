@@ -36,7 +36,16 @@ def main():
            "`H`), device-resident inputs, best of two timed runs after a warm-up; `fused` = `k_fused_wide` (float32) / `k_fused_wide64`",
            "(float64) forced through the tuning bits, `two contractions` = `k_gemm2` / `k_gemm_nt` (`EVC_FLAG_NO_FUSED`). Utterances of",
            "688 frames.  Raw lines: `r04_tune_routing_k20.jsonl`, `r04_tune_routing_k80.jsonl`.  `use_wide` (`evc_api.hip`) is written",
-           "from these tables; the fractions are of whole calls, so they sit below `bench.py`'s loop-only `roofline.frac`.", ""]
+           "from these tables; the fractions are of whole calls, so they sit below `bench.py`'s loop-only `roofline.frac`.",
+           "",
+           "The float32 rows were measured twice.  The first sweep of this round forced the fused kernel with the tuning value 4 =",
+           "FOUR wavefronts per workgroup at every batch size - not the layout the library picks from 512 frame tiles on - and so",
+           "undervalued it at the large batches (16 utterances, M = 201, N = 4096: 0.521 against the 0.656 below); those lines are kept",
+           "as `r04_tune_routing_k{20,80}_f32_w4.jsonl`.  The rows below are 8 wavefronts per workgroup (the only layout since the",
+           "static schedule, `r04_wide_small_batches.md`), after the first-ticket fix (`r04_wide_split_launch.md`).  The float64 rows",
+           "M = 257 / 513 are from before those two changes (re-measured after the ticket fix: within 0.01; the static schedule only",
+           "touches one to three utterances, where the two contractions stay ahead), M = 201 / 160 (3 whole bin tiles per wavefront)",
+           "from after the ticket fix.", ""]
     for k in (80, 20):
         table(os.path.join(ROOT, "profiles", f"r04_tune_routing_k{k}.jsonl"), out)
     open(os.path.join(ROOT, "profiles", "r04_routing_table.md"), "w").write("\n".join(out) + "\n")

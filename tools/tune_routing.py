@@ -52,14 +52,14 @@ def main():
                 Ad = torch.from_numpy(A.astype(npdt)).cuda()
                 Xall = (A[rng.integers(0, N, 688 * 64)] * rng.random((688 * 64, 1)) + 1e-6).astype(npdt)
                 Xd_all = torch.from_numpy(Xall).cuda()
-                for U in ((2, 4, 6, 8, 12, 16, 32, 64) if quick else (1, 2, 4, 6, 8, 12, 16, 24, 32, 64)):
+                for U in ((1, 2, 3, 4, 6, 8, 12, 16, 32, 64) if quick else (1, 2, 4, 6, 8, 12, 16, 24, 32, 64)):
                     T = 688 * U
                     if dt == "f64" and N * T * 8 > 6e9:       # H alone beyond 6 GB: skip the corner
                         continue
                     offs = np.arange(U + 1, dtype=np.int32) * 688
                     Xd = Xd_all[:T]
                     tg, ig = timed(Ad, Xd, K, offs, fused=False)
-                    tf, if_ = timed(Ad, Xd, K, offs, fused_w=3 if (dt == "f64" and M <= 208) else 4)
+                    tf, if_ = timed(Ad, Xd, K, offs, fused_w=(3 if M <= 208 else 4) if dt == "f64" else 8)
                     _, idef = timed(Ad, Xd, 1, offs)
                     fl = K * (4.0 * M * N + 3.0 * N) * T
                     print(json.dumps({"dtype": dt, "M": M, "N": N, "utterances": U, "frame_tiles": (T + 15) // 16, "K": K,
