@@ -255,6 +255,10 @@ def kernel_instance(kernel_tag, M, members, loss):
         msteps = (M + 3) // 4 if M <= 16 else 4 + (M - 16 + 3) // 4
         c = members if members in (1, 2, 4) else (0 if members in (8, 16, 32, 64) else -1)
         return f"k_fused_all<{msteps}, {c}, {'true' if loss == 'kl' else 'false'}>"
+    if kernel_tag == "k_fused_wide64":      # whole bin tiles per wavefront (evc_wide64.hip, WIDE64_TPW_SET)
+        return "k_fused_wide64<%d>" % next((v for v in (3, 4, 5, 7, 8) if 64 * v + 16 >= M), 8)
+    if kernel_tag == "k_fused_wide":        # bin tiles, 8 wavefronts per workgroup (evc_wide.hip, WIDE_MT_SET)
+        return "k_fused_wide<%d, 8>" % next((v for v in (4, 6, 8, 10, 13) if 16 * v >= M), 13)
     return None
 
 
