@@ -717,14 +717,22 @@ WideLayout wide_layout(int M, int N, int T_, int n_cus, int c_req, int w_req) {
     // 230.9 - profiles/r04_wide_small_batches.md)
     f.W = w_req == 4 || w_req == 8 ? w_req : 8;
     f.G = (f.TT + f.W - 1) / f.W;
-    // ranges per frame group: enough tasks per iteration to keep every CU busy (none when the groups alone do)
-    // (never more tasks per iteration than workgroups when the ranges are many: the surplus would wait a whole task)
-    int c = c_req > 0 ? c_req : (f.G >= n_cus ? 1 : (f.G * 4 >= n_cus ? (n_cus + f.G - 1) / f.G : n_cus / f.G));
+    // ranges per frame group (round 4, profiles/r04_wide_small_batches.md):
+    //  * 32 groups or more (six utterances of 688 frames on): ceil(CUs / G) <= 8 ranges, every sweep task adds up the
+    //    partials of its group itself (no reduce tasks) and the ticket queue absorbs the few tasks beyond the CU count
+    //    (8 utterances, 43 groups: 6 ranges = 258 tasks, 0.570 of the peak; 5 ranges on the static schedule: 0.529);
+    //  * fewer groups: floor(CUs / G) ranges - never more sweep tasks than workgroups, so that the static schedule
+    //    applies - and, beyond four ranges, a reduce slice per task so that the traffic stays linear in c
+    //    (5 utterances, 27 groups: 9 ranges + slices 0.524; 10 ranges without: 0.501).
+    int c = c_req > 0 ? c_req : (f.G >= n_cus ? 1 : (f.G * 8 >= n_cus ? (n_cus + f.G - 1) / f.G : n_cus / f.G));
     const int cmax = f.NB / 2 > 0 ? f.NB / 2 : 1;
     if (c > cmax) c = cmax;
     if (c > 64) c = 64;
     f.c = c;
-    f.rmode = c > 4 ? 1 : 0;
+    f.rmode = (c > 8 || (c > 4 && f.G * c <= n_cus)) ? 1 : 0;
+#ifdef EVC_WIDE_STAMP      // (the stand-alone harness only)
+    if (getenv("EVC_WIDE_RMODE_MIN")) f.rmode = c >= atoi(getenv("EVC_WIDE_RMODE_MIN")) ? 1 : 0;
+#endif
     const size_t tile = (size_t)f.MT * 256;      // floats per V tile
     f.aw = (size_t)f.NB * 2 * tile;
     f.xw = (size_t)f.G * f.W * tile;

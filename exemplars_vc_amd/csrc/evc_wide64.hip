@@ -761,6 +761,9 @@ Wide64Layout wide64_layout(int M, int N, int T_, int n_cus, int c_req, int tpw_r
     f.TT = (T_ + 15) / 16;
     f.G = (f.TT + 1) / 2;
     if (n_cus <= 0) n_cus = 256;
+    // (evc_wide.hip's round-4 rule - from 32 groups on up to 8 ranges without reduce tasks - was measured here too and
+    // lost: two utterances of the C3 shape, 43 groups: 6 ranges through the queue 0.481 of the peak, 5 ranges with
+    // reduce slices on the static schedule 0.547)
     int c = c_req > 0 ? c_req : (f.G >= n_cus ? 1 : (f.G * 4 >= n_cus ? (n_cus + f.G - 1) / f.G : n_cus / f.G));
     const int cmax = f.NB / 2 > 0 ? f.NB / 2 : 1;
     if (c > cmax) c = cmax;
