@@ -190,12 +190,13 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
         if (tk >= total) break;
         __syncthreads();                       // everybody has read the ticket before thread 0 replaces it
         const unsigned itl = tk / per_it, rem = tk - itl * per_it;
-        if (tid == 0) {                        // the next ticket is requested now and used at the end of this task
-            if (a.static_q)                    // (static: this workgroup's reduce slice, then its sweep of the next iteration)
-                nxt = (a.rmode && rem < GC) ? tk + GC : (itl + 1) * per_it + blockIdx.x;
-            else
-                nxt = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        // The next ticket: static schedule - this workgroup's reduce slice, then its sweep of the next iteration.  Ticket
+        // queue - drawn from the counter when this task is FINISHED (rounds 3 and early 4 requested it here, at the start,
+        // to hide the atomic's latency: tickets were then bound to workgroups a whole task before they became free, and with
+        // a few more tasks per iteration than CUs a launch fell into a slow pattern about one time in three - 8 utterances
+        // of the STFT flow: 28.0 - 28.5 ms or 34.5 - 35.8 ms per 150 iterations; drawn late: 26.0 - 26.4 ms every time, and
+        // every batch size gained, 16 utterances 50.4 -> 49.4 ms)
+        if (tid == 0 && a.static_q) nxt = (a.rmode && rem < GC) ? tk + GC : (itl + 1) * per_it + blockIdx.x;
         const int it = a.it_begin + (int)itl;
         const bool reduce = rem >= GC;
         const unsigned idx = reduce ? rem - GC : rem;
@@ -238,6 +239,7 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
             WSTAMP(4);
             if (tid == 0) {
                 __hip_atomic_fetch_add(a.done_r + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!a.static_q) nxt = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s_ctl[0] = nxt;
             }
             __syncthreads();
@@ -289,6 +291,7 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
             __syncthreads();
             if (tid == 0) {
                 __hip_atomic_fetch_add(a.done + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!a.static_q) nxt = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s_ctl[0] = nxt;
             }
             __syncthreads();
@@ -560,6 +563,7 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
         WSTAMP(4);
         if (tid == 0) {
             __hip_atomic_fetch_add(a.done + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!a.static_q) nxt = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_ctl[0] = nxt;
         }
         __syncthreads();

@@ -195,12 +195,9 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
         if (tk >= total) break;
         __syncthreads();
         const unsigned itl = tk / per_it, rem = tk - itl * per_it;
-        if (tid == 0) {
-            if (a.static_q)        // (no ticket counter: this workgroup's reduce slice, then its sweep of the next iteration - see k_fused_wide)
-                nxt = (a.rmode && rem < GC) ? tk + GC : (itl + 1) * per_it + blockIdx.x;
-            else
-                nxt = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        // (static schedule: this workgroup's reduce slice, then its sweep of the next iteration; ticket queue: drawn when
+        // the task is finished - see k_fused_wide)
+        if (tid == 0 && a.static_q) nxt = (a.rmode && rem < GC) ? tk + GC : (itl + 1) * per_it + blockIdx.x;
         const int it = a.it_begin + (int)itl;
         const bool reduce = rem >= GC;
         const unsigned idx = reduce ? rem - GC : rem;
@@ -239,6 +236,7 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
             W64STAMP(4);
             if (tid == 0) {
                 __hip_atomic_fetch_add(a.done_r + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!a.static_q) nxt = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s_ctl[0] = nxt;
             }
             __syncthreads();
@@ -308,6 +306,7 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
             __syncthreads();
             if (tid == 0) {
                 __hip_atomic_fetch_add(a.done + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!a.static_q) nxt = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s_ctl[0] = nxt;
             }
             __syncthreads();
@@ -596,6 +595,7 @@ __global__ __launch_bounds__(256, 1) void k_fused_wide64(Wide64Args a) {
         W64STAMP(4);
         if (tid == 0) {
             __hip_atomic_fetch_add(a.done + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!a.static_q) nxt = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_ctl[0] = nxt;
         }
         __syncthreads();

@@ -72,7 +72,7 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e30f;
-    for (int rep = 0; rep < 4; ++rep) {
+    for (int rep = 0; rep < (getenv("WB_REPS") ? atoi(getenv("WB_REPS")) : 4); ++rep) {
         CK(wide_begin(f, b, 0));
         CK(hipEventRecord(e0, 0));
         if (split <= 0) {
@@ -91,6 +91,7 @@ int main(int argc, char** argv) {
         CK(hipEventSynchronize(e1));
         float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
         if (ms < best) best = ms;
+        if (getenv("WB_VERBOSE")) printf("rep %d: %.3f ms\n", rep, ms);
     }
     const double fl = (double)K * (4.0 * M * N + 3.0 * N) * T;
     printf("launch %.3f ms = %.1f us per iteration, %.1f Tflop/s = %.3f of 157.3\n", best, 1e3 * best / (K + 1),
