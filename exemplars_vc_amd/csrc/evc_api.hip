@@ -535,24 +535,23 @@ WideWs<T> carve_wide(void* base, const Dims& d, int n_slots, int n_cus, bool wit
     return w;
 }
 // Routing between the fused task-queue kernels and the two contractions, from the measured table
-// profiles/r04_routing_table.md (tools/tune_routing.py: whole calls, K = 20 and K = 80, N in {1024, 4096, 16384}, 1 .. 64
-// utterances of 688 frames; round 3 had measured one (M, N) point per kernel):
-//  * float32 (k_fused_wide, 32 < M <= 208), 8 wavefronts per workgroup and - up to ~5 utterances - the static schedule
-//    (profiles/r04_wide_small_batches.md): ahead of the two contractions from one utterance on at N = 16384 (M = 201:
-//    0.476 / 0.413 of the peak), from two (M = 201) or three (M = 64) at N = 4096 (0.384 / 0.338; 0.259 / 0.203), from six
-//    at N = 1024 (0.338 / 0.302), and by more and more towards 64 utterances (M = 201, N = 4096: 0.705 / 0.526; the first
-//    sweep of this round had forced FOUR wavefronts per workgroup at every size and found the opposite).  One utterance
-//    at N = 4096 stays with the two contractions (0.272 / 0.296: two hand-offs of ~11 us per iteration beside 22 us of
-//    block steps).
-//  * float64 (k_fused_wide64, 144 < M <= 528; 208 < M here, M <= 208 below): wins from four utterances (172 frame tiles) on - M = 513: 0.615 / 0.563
-//    at N = 4096, 0.653 / 0.619 at 16384, 0.49 / 0.42 at 1024 - up to ~24 utterances for N >= 2048 (32: 0.672 / 0.680;
-//    64: 0.674 / 0.721) and up to ~32 for smaller dictionaries (N = 1024: 0.649 / 0.632 at 32, 0.650 / 0.700 at 64).
-//    At M = 257 (4 bin tiles per wavefront: fewer MFMAs per block against the same fixed work) the window closes
-//    earlier: N < 2048 like above, 2048 <= N < 8192 up to ~14 utterances, from N = 8192 on the two contractions win
-//    throughout (0.549 / 0.596 at six utterances, N = 16384).  One and two utterances: the static schedule brought the
-//    fused kernel from 0.35 to 0.55 of the peak at the C3 shape, the two contractions give 0.60 / 0.65.
+// profiles/r04_routing_table.md (tools/tune_routing.py on the final build: whole calls, K = 20 and K = 80, N in {1024, 4096,
+// 16384}, 1 .. 64 utterances of 688 frames; fractions of the matrix peak, fused / two contractions at K = 80):
+//  * float32 (k_fused_wide, 32 < M <= 208): ahead from one utterance on at N = 16384 (M = 201: 0.49 / 0.42), from two
+//    (M = 201: 0.39 / 0.34) or three (M = 64: 0.26 / 0.20) at N = 4096, from six at N = 1024 (0.42 / 0.30), and by more and
+//    more towards 64 utterances (M = 201, N = 4096: 0.71 / 0.53).  One utterance at N = 4096 stays with the two
+//    contractions (0.28 / 0.30: two hand-offs of ~11 us per iteration beside 22 us of block steps).
+//  * float64 (k_fused_wide64, 144 < M <= 528): small dictionaries (N = 1024) from one utterance on (M = 513: 0.26 / 0.22,
+//    three utterances 0.47 / 0.35) up to ~32 (64: 0.64 / 0.69).  N >= 2048: two utterances lose (M = 513, N = 4096:
+//    0.50 / 0.61 - five ranges with reduce slices against the contractions' best case), three win (0.60 / 0.53: 260 tasks
+//    through the queue) and so do four to ~24 (16: 0.66 / 0.62; 32: 0.67 / 0.67; 64: 0.67 / 0.71).  At M = 257 (4 bin tiles
+//    per wavefront: fewer MFMAs per block against the same fixed work) the window closes earlier: 2048 <= N < 8192 up to
+//    ~14 utterances (16: 0.55 / 0.55), from N = 8192 on the two contractions win or tie throughout (six utterances at
+//    N = 16384: 0.55 / 0.59).  176 < M <= 208 (3 bin tiles per wavefront, 0.49 - 0.52): N < 8192 like the others up to ~45
+//    utterances (32: 0.51 / 0.49, 64: 0.51 / 0.58), from 8192 on only where the contractions' tile counts fall badly
+//    (12 - 32 utterances: 0.51 - 0.52 / 0.40 - 0.47); M <= 176 pads more than a thirteenth of the tile slots and stays out
+//    (M = 160: 0.42).
 // The tuning bits (ranges, wavefronts / bin tiles) force the fused kernel at any size.
-constexpr int WIDE64_MIN_TILES = 172;
 bool use_wide(int M, int N, int T_, int dtype, int algo, int loss, int reserved) {
     if (reserved & EVC_FLAG_NO_FUSED) return false;
     // the task queues hand partial sums from workgroup to workgroup inside a launch and the call reads one word back at
@@ -563,21 +562,17 @@ bool use_wide(int M, int N, int T_, int dtype, int algo, int loss, int reserved)
     if (dtype == EVC_F64) {
         if (!wide64_supported(M, N, T_, dtype, algo, loss)) return false;
         if (forced) return true;
+        const int lo64 = N < 2048 ? 43 : 100;
         if (M <= 208) {
-            // 3 whole bin tiles per wavefront + the split one (round 4; profiles/r04_routing_table.md, f64 M = 201 / 160):
-            // 0.52 of the peak from six utterances on where the two contractions give 0.39 - 0.49 (STFT flow in float64,
-            // 16 utterances: 83.3 k against 74.4 k frames/s); from ~48 utterances on they win again (0.58 at 64), and
-            // with fewer than 12 of the 13 tile slots used (M <= 176: 0.42 at M = 160) throughout
             if (M <= 176) return false;
-            const int lo = N < 2048 ? WIDE64_MIN_TILES : (N < 8192 ? 240 : 500);
-            return tiles >= lo && tiles <= 2000;
+            return tiles >= (N < 8192 ? lo64 : 500) && tiles <= 2000;
         }
         const int hi = N < 2048 ? 1400 : (M >= 400 ? 1000 : (N < 8192 ? 600 : 0));
-        return tiles >= WIDE64_MIN_TILES && tiles <= hi;
+        return tiles >= lo64 && tiles <= hi;
     }
     if (!wide_supported(M, N, T_, dtype, algo)) return false;
     if (forced) return true;
-    const int lo = N >= 8192 ? 43 : (N >= 2048 ? (M > 96 ? 86 : 129) : (M > 96 ? 240 : 300));
+    const int lo = N >= 8192 ? 43 : (N >= 2048 ? (M > 96 ? 86 : 129) : 240);
     return tiles >= lo;
 }
 

@@ -37,10 +37,15 @@
  *         asynchronous (at about half the speed for a lone utterance, ~10 % less for large batches);
  *     (3) evc_nmf_solve / evc_nmf_convert on the task-queue kernels for wide spectra (k_fused_wide: float32,
  *         32 < M <= 208, from one to six utterances on depending on the dictionary size; k_fused_wide64: float64,
- *         176 < M <= 528, 4 .. ~30 utterances):
+ *         176 < M <= 528, 3 .. ~30 utterances, small dictionaries from one):
  *         the same round trip, taken BEFORE anything is written to H or Y, so that a solve whose wait ran out is
  *         redone on the two-contraction path from the untouched inputs (evc_solve_info.redo = 1).  Round 3 delivered
- *         NaN under status 0 there.  EVC_FLAG_NO_EXCHANGE routes away from these kernels too.
+ *         NaN under status 0 there.  EVC_FLAG_NO_EXCHANGE routes away from these kernels too.  Batches of up to ~5
+ *         utterances run these kernels on a static schedule (one task per workgroup and iteration) that needs all its
+ *         workgroups resident at once, like k_fused_all's exchange: two such solves started concurrently on two streams
+ *         can starve each other until the bounded waits run out (seconds) and both are redone - give concurrent
+ *         small solves EVC_FLAG_NO_EXCHANGE (the compat layer's side streams do).  Larger batches draw tasks from a
+ *         queue and depend on nobody's residency.
  *   No global mutable state: calls on distinct streams/devices are independent and the
  *   caller's current device (hipSetDevice) is honoured.  Nothing is read from the process environment.
  *   Host arrays (utt_offsets, frame_offsets, a_offsets / b_offsets) are consumed before the call returns: they are

@@ -59,8 +59,8 @@ def test_wide64_routing_by_batch_size():
         got, info = evc.solve_activations(p["A"], p["X"], iters=4, eps_mode="zero_replace", init="sklearn", info=True)
         assert info["kernel"] == kernel, info
         check(got, sk_want(o, p["A"], p["X"], 4))
-    # 3 whole bin tiles per wavefront (176 < M <= 208): from 240 frame tiles on at N >= 2048, from 172 below
-    for M, T, kernel in ((201, 4000, "k_fused_wide64"), (201, 1000, "k_gemm_nt"), (170, 4000, "k_gemm_nt")):
+    # 3 whole bin tiles per wavefront (176 < M <= 208): from 100 frame tiles on at N >= 2048, from 43 below
+    for M, T, kernel in ((201, 4000, "k_fused_wide64"), (201, 500, "k_gemm_nt"), (170, 4000, "k_gemm_nt")):
         p = o.synth_problem(M, 256, T, seed=T + M)
         got, info = evc.solve_activations(p["A"], p["X"], iters=4, eps_mode="zero_replace", init="sklearn", info=True)
         assert info["kernel"] == kernel, info

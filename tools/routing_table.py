@@ -38,14 +38,11 @@ def main():
            "688 frames.  Raw lines: `r04_tune_routing_k20.jsonl`, `r04_tune_routing_k80.jsonl`.  `use_wide` (`evc_api.hip`) is written",
            "from these tables; the fractions are of whole calls, so they sit below `bench.py`'s loop-only `roofline.frac`.",
            "",
-           "The float32 rows were measured twice.  The first sweep of this round forced the fused kernel with the tuning value 4 =",
-           "FOUR wavefronts per workgroup at every batch size - not the layout the library picks from 512 frame tiles on - and so",
-           "undervalued it at the large batches (16 utterances, M = 201, N = 4096: 0.521 against the 0.656 below); those lines are kept",
-           "as `r04_tune_routing_k{20,80}_f32_w4.jsonl`.  The rows below are 8 wavefronts per workgroup (the only layout since the",
-           "static schedule, `r04_wide_small_batches.md`), after the first-ticket fix (`r04_wide_split_launch.md`).  The float64 rows",
-           "M = 257 / 513 are from before those two changes (re-measured after the ticket fix: within 0.01; the static schedule only",
-           "touches one to three utterances, where the two contractions stay ahead), M = 201 / 160 (3 whole bin tiles per wavefront)",
-           "from after the ticket fix.", ""]
+           "Every row is of the final build of round 4 (first tickets by index, later tickets drawn when a task is finished, static",
+           "schedule for small batches, 8 wavefronts per workgroup, `k_fused_wide64<3>`), except M = 160, which predates the late",
+           "tickets.  An earlier float32 sweep of this round had forced FOUR wavefronts per workgroup at every batch size and",
+           "undervalued the fused kernel at the large batches (16 utterances, M = 201, N = 4096: 0.521 against the 0.69 below);",
+           "its lines are kept as `r04_tune_routing_k{20,80}_f32_w4.jsonl`.", ""]
     for k in (80, 20):
         table(os.path.join(ROOT, "profiles", f"r04_tune_routing_k{k}.jsonl"), out)
     open(os.path.join(ROOT, "profiles", "r04_routing_table.md"), "w").write("\n".join(out) + "\n")
