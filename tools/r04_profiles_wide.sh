@@ -5,11 +5,11 @@
 OUT=gpurun_out/r04w
 mkdir -p $OUT
 : > $OUT/bench_wide.jsonl
-for U in 1 2 3 4 6 8 16 32 64; do
+for U in 16; do
   python3 bench.py --config STFT --utterances $U --steps 3 --warmup 1 --no-cpu --no-pcie >> $OUT/bench_wide.jsonl 2>> $OUT/bench.err
 done
 python3 bench.py --config STFT64 --steps 3 --warmup 1 --no-cpu --no-pcie >> $OUT/bench_wide.jsonl 2>> $OUT/bench.err
-for U in 1 2 4 16; do
+for U in 16; do
   python3 bench.py --config C3 --utterances $U --steps 2 --warmup 1 --no-cpu --no-pcie >> $OUT/bench_wide.jsonl 2>> $OUT/bench.err
 done
 echo "bench lines done" >&2
