@@ -74,6 +74,30 @@ def test_c3_batch_of_16_utterances_on_the_fused_float64_kernel():
     np.testing.assert_allclose(Y[:128].cpu().numpy(), Yw, rtol=1e-10, atol=1e-14 * float(np.abs(Yw).max()))
 
 
+@pytest.mark.parametrize("N,U,kernel", [(8192, 3, "k_fused_wide64"), (8192, 2, "k_gemm_nt"), (1024, 1, "k_fused_wide64"),
+                                        (1024, 2, "k_fused_wide64")])
+def test_c3_width_small_batches_by_the_round_4_routing(N, U, kernel):
+    """Round 4's routing table (profiles/r04_routing_table.md): at M = 513 three utterances go to k_fused_wide64 (260 tasks
+    through the ticket queue), two stay on the two contractions; small dictionaries run the fused kernel from one utterance
+    on (the static schedule: one sweep task per workgroup).  A 48-frame slice against the float64 oracle each."""
+    import torch
+    import exemplars_vc_amd as evc
+    o = oracle()
+    M, K, T = 513, 60, 688
+    p = o.synth_problem(M, N, T, seed=N + U)
+    A, B, X, offs = _batch_of_copies(p, U)
+    dev = torch.device("cuda:0")
+    At, Xt = torch.from_numpy(A).to(dev), torch.from_numpy(X).to(dev)
+    H, info = evc.solve_activations(At, Xt, layout="frame_major", iters=K, eps_mode="zero_replace", init="sklearn",
+                                    utt_offsets=offs, info=True)
+    assert info["kernel"] == kernel and info["redo"] == 0, info
+    want = _slice_want(o, A, X, K, 48, float(np.sqrt(X[:T].mean() / N)))
+    r, z = rel_err(H[:48].cpu().numpy().T, want)
+    assert r <= RTOL64 and z == 0.0, f"M=513 N={N} x{U} slice ({info['kernel']}): max rel err {r:.3e}"
+    if U > 1:
+        assert float((H[(U - 1) * T:(U - 1) * T + 64] - H[:64]).abs().max() / H[:64].abs().max()) <= 1e-12
+
+
 def test_c3_one_call_of_16384_frames():
     """BASELINE.md C3, "T = 16 384": 1024 frame tiles - beyond k_fused_wide64's window, the two contractions serve it"""
     import torch
