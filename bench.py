@@ -258,7 +258,8 @@ def kernel_instance(kernel_tag, M, members, loss):
     if kernel_tag == "k_fused_wide64":      # whole bin tiles per wavefront (evc_wide64.hip, WIDE64_TPW_SET)
         return "k_fused_wide64<%d>" % next((v for v in (3, 4, 5, 7, 8) if 64 * v + 16 >= M), 8)
     if kernel_tag == "k_fused_wide":        # bin tiles, 8 wavefronts per workgroup (evc_wide.hip, WIDE_MT_SET)
-        return "k_fused_wide<%d, 8>" % next((v for v in (4, 6, 8, 10, 13) if 16 * v >= M), 13)
+        # (third argument: tagged hand-offs, the static schedule of batches up to ~5 utterances - not derivable here)
+        return "k_fused_wide<%d, 8, false>" % next((v for v in (4, 6, 8, 10, 13) if 16 * v >= M), 13)
     return None
 
 

@@ -537,10 +537,9 @@ WideWs<T> carve_wide(void* base, const Dims& d, int n_slots, int n_cus, bool wit
 // Routing between the fused task-queue kernels and the two contractions, from the measured table
 // profiles/r04_routing_table.md (tools/tune_routing.py on the final build: whole calls, K = 20 and K = 80, N in {1024, 4096,
 // 16384}, 1 .. 64 utterances of 688 frames; fractions of the matrix peak, fused / two contractions at K = 80):
-//  * float32 (k_fused_wide, 32 < M <= 208): ahead from one utterance on at N = 16384 (M = 201: 0.49 / 0.42), from two
-//    (M = 201: 0.39 / 0.34) or three (M = 64: 0.26 / 0.20) at N = 4096, from six at N = 1024 (0.42 / 0.30), and by more and
-//    more towards 64 utterances (M = 201, N = 4096: 0.71 / 0.53).  One utterance at N = 4096 stays with the two
-//    contractions (0.28 / 0.30: two hand-offs of ~11 us per iteration beside 22 us of block steps).
+//  * float32 (k_fused_wide, 32 < M <= 208): ahead from one utterance on at every N and M measured (M = 201: 0.52 / 0.42 at
+//    N = 16384, 0.34 / 0.29 at 4096, 0.16 / 0.13 at 1024), and by more and more towards 64 utterances (M = 201, N = 4096:
+//    0.71 / 0.53).
 //  * float64 (k_fused_wide64, 144 < M <= 528): small dictionaries (N = 1024) from one utterance on (M = 513: 0.26 / 0.22,
 //    three utterances 0.47 / 0.35) up to ~32 (64: 0.64 / 0.69).  N >= 2048: two utterances lose (M = 513, N = 4096:
 //    0.50 / 0.61 - five ranges with reduce slices against the contractions' best case), three win (0.60 / 0.53: 260 tasks
@@ -572,8 +571,10 @@ bool use_wide(int M, int N, int T_, int dtype, int algo, int loss, int reserved)
     }
     if (!wide_supported(M, N, T_, dtype, algo)) return false;
     if (forced) return true;
-    const int lo = N >= 8192 ? 43 : (N >= 2048 ? (M > 96 ? 86 : 129) : 240);
-    return tiles >= lo;
+    // (with tagged hand-offs on the static schedule - the last change of round 4 - the fused kernel is ahead from one
+    // utterance of 688 frames on at every (M, N) measured: M = 201, N = 4096: 0.34 / 0.29 at one, 0.49 / 0.34 at two;
+    // N = 1024: 0.16 / 0.13; M = 64, N = 4096: 0.21 / 0.15.  Shorter inputs were not measured and stay where they were.)
+    return tiles >= 43;
 }
 
 template <typename T>

@@ -229,6 +229,7 @@ struct WideLayout {
     int NB;              // exemplar blocks of 16
     int TT, G;           // frame tiles, frame groups of W tiles
     int c, rmode;        // exemplar ranges per group; 1: a reduce task sums the partial V' (c > 4)
+    int tagged;          // 1: static schedule with reduce slices - the hand-offs carry their arrival flag in the data (evc_wide.hip)
     size_t aw, xw, hw, vpart, vsum;      // element counts (Pw has hw elements)
 };
 struct WideBuffers {

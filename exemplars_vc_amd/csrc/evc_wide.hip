@@ -77,6 +77,11 @@ struct WideArgs {
     // that finished early drew a reduce task whose group was still sweeping and sat on it (1 utterance: 30 us of a
     // reduce task's 36, 4 utterances: 97 of 106 - profiles/r04_wide_small_batches.md)
     int static_q;
+    // 1 (static schedule with reduce slices only): no counters - every published float carries the hand-off's epoch bit
+    // ((iteration >> 1) & 1; the slots alternate by iteration parity) in its lowest mantissa bit, readers poll the data
+    // itself and clear the bit.  Takes the store drain, the counter and the poll of the counter out of both hand-offs of
+    // an iteration; costs every partial sum at most one float32 ulp (as k_fused_all's exchange does in float64).
+    int tagged;
     float* Hs;               // [slots][hs_stride]
     size_t hs_stride;
     double* err2s;           // [slots][err_stride]
@@ -117,7 +122,9 @@ __device__ unsigned long long* evc_wide_dbg = nullptr;        // [tasks of the l
 #define WNOTE(k, v)
 #endif
 
-template <int MT, int W>
+// TG: the instance with tagged hand-offs (WideArgs.tagged).  As a run-time flag in one instance the extra code cost the
+// other schedules 5 % (16 utterances of the STFT flow: 0.686 -> 0.646 of the peak over the whole call).
+template <int MT, int W, bool TG>
 __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
 #ifdef EVC_WIDE_STAGGER          // diagnostic build: see "Stagger" below - measured slower, off
     constexpr bool STAGGER = W == 8;
@@ -148,8 +155,29 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
         nxt = blockIdx.x;
         s_ctl[0] = nxt;
         s_ctl[1] = 1u;
+        s_ctl[2] = 0u;                         // tagged hand-offs: a bounded poll of the data ran out
     }
     __syncthreads();
+    // tagged hand-offs (WideArgs.tagged): the epoch bit rides in the lowest mantissa bit of every float
+    auto tag_set = [](f32x4 v, unsigned tg) -> f32x4 {
+        u32x4 b = __builtin_bit_cast(u32x4, v);
+        b = (b & ~1u) | tg;
+        return __builtin_bit_cast(f32x4, b);
+    };
+    auto tag_clear = [](f32x4 v) -> f32x4 {
+        u32x4 b = __builtin_bit_cast(u32x4, v);
+        b = b & ~1u;
+        return __builtin_bit_cast(f32x4, b);
+    };
+    auto tag_bad = [](f32x4 v, unsigned tg) -> unsigned {      // != 0: some float of v does not carry epoch bit tg yet
+        const u32x4 b = __builtin_bit_cast(u32x4, v);
+        return ((b[0] ^ tg) | (b[1] ^ tg) | (b[2] ^ tg) | (b[3] ^ tg)) & 1u;
+    };
+    auto poll_gave_up = [&](long spins) -> bool {
+        return spins > WIDE_SPIN_LIMIT ||
+               ((spins & 63) == 0 && __hip_atomic_load(a.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
+    };
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
 
     // thread 0 polls a counter until it reaches `need`; false (for every thread) when the solve was aborted
     auto wait_for = [&](const unsigned* ctr, unsigned need) -> bool {
@@ -208,41 +236,71 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
 
         if (reduce) {
             // ---- reduce task: slice e of the group's V' = sum over the c ranges, in range order ----
-            if (!wait_for(a.done + g, c * (unsigned)(it + 1))) break;
+            if (!TG && !wait_for(a.done + g, c * (unsigned)(it + 1))) break;
             WSTAMP(1);
+            const unsigned tg = ((unsigned)it >> 1) & 1u;         // (tagged) epoch bit of this iteration's partials and sums
             const unsigned U = W * MT * 64;                       // 16-byte units of a group's partial
             const unsigned lo = (unsigned)((unsigned long)e * U / c), hi = (unsigned)((unsigned long)(e + 1) * U / c);
             const __amdgpu_buffer_rsrc_t rin = make_rsrc(a.Vpart + ((size_t)(par * a.G + g) * c) * U * 4, c * U * 16u);
             const __amdgpu_buffer_rsrc_t rout = make_rsrc(a.Vsum + (size_t)(par * a.G + g) * U * 4, U * 16u);
-            // (sharing a unit's c partials between thread sets - one batch of loads in flight instead of two - shortened the
-            // sum from 5.8 to 4.8 us at c = 42 and lengthened the wait in front of it by as much: the task ends when the
-            // slowest member's partial has arrived, not when this workgroup has added up; dropped)
+            // (sharing a unit's c partials between thread sets - one batch of loads in flight instead of two in a row - was
+            // tried twice: with counters the wait for the slowest member stood in front of it either way (sum 5.8 -> 4.8 us,
+            // wait 6.4 -> 7.6), with tagged hand-offs a step stayed at 43.0 us against 42.3; dropped)
             for (unsigned un = lo + tid; un < hi; un += W * 64) {
+                // (tagged: units of frame tiles beyond the batch are never published - wavefronts without frames store
+                // nothing - and never read: not waited for)
+                if (TG && g * W + (int)(un / (MT * 64)) >= a.TT) continue;
                 // 24 loads in flight at a time (each is a memory round trip), summed in range order
                 f32x4 acc = f32x4{0, 0, 0, 0};
                 for (unsigned m0 = 0; m0 < c; m0 += 24) {
                     f32x4 v[24];
+                    for (long spins = 0;;) {
 #pragma unroll
-                    for (unsigned k = 0; k < 24; ++k) {
-                        const unsigned m = m0 + k < c ? m0 + k : c - 1;
-                        v[k] = ld_sc1(rin, (m * U + un) * 16u);
+                        for (unsigned k = 0; k < 24; ++k) {
+                            const unsigned m = m0 + k < c ? m0 + k : c - 1;
+                            v[k] = ld_sc1(rin, (m * U + un) * 16u);
+                        }
+                        if (!TG) break;
+                        unsigned bad = 0;
+#pragma unroll
+                        for (unsigned k = 0; k < 24; ++k) bad |= tag_bad(v[k], tg);
+                        if (!bad) break;                          // (a partial that has not arrived is fetched again)
+                        if (poll_gave_up(++spins)) {
+                            s_ctl[2] = 1u;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
                     }
 #pragma unroll
-                    for (unsigned k = 0; k < 24; ++k)
-                        if (m0 + k < c) acc = (m0 + k) ? acc + v[k] : v[k];
+                    for (unsigned k = 0; k < 24; ++k) {
+                        const f32x4 vk = TG ? tag_clear(v[k]) : v[k];
+                        if (m0 + k < c) acc = (m0 + k) ? acc + vk : vk;
+                    }
                 }
-                st_sc1(rout, un * 16u, acc);
+                st_sc1(rout, un * 16u, TG ? tag_set(acc, tg) : acc);
             }
             WSTAMP(3);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            if (TG) {
+                lds_barrier();                                    // (the stores stay in flight: readers poll the data)
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
             WSTAMP(4);
             if (tid == 0) {
-                __hip_atomic_fetch_add(a.done_r + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!TG) __hip_atomic_fetch_add(a.done_r + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (!a.static_q) nxt = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s_ctl[0] = nxt;
             }
-            __syncthreads();
+            if (TG) {
+                lds_barrier();
+                if (s_ctl[2]) {                                   // a partial never arrived: void the solve, everybody leaves
+                    if (tid == 0) __hip_atomic_store(a.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            } else {
+                __syncthreads();
+            }
             WSTAMP(5);
             continue;
         }
@@ -276,7 +334,7 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
             }
             grp_live = __ballot(grp_live ? 1 : 0) != 0;
         }
-        if (it > 0 && !wait_for(a.rmode ? a.done_r + g : a.done + g, c * (unsigned)it)) break;
+        if (!TG && it > 0 && !wait_for(a.rmode ? a.done_r + g : a.done + g, c * (unsigned)it)) break;
         WSTAMP(1);
         if (it > 0 && !grp_live) {
             // A frame group whose utterances have all stopped (or that is padding) does not sweep: its H stays, and so
@@ -284,17 +342,45 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
             if (on) {
                 const __amdgpu_buffer_rsrc_t rsrc = make_rsrc(a.Vpart + ((((size_t)((par ^ 1u) * a.G + g) * c + e) * W + w)) * (TILE_B / 4), TILE_B);
                 const __amdgpu_buffer_rsrc_t rdst = make_rsrc(a.Vpart + ((((size_t)(par * a.G + g) * c + e) * W + w)) * (TILE_B / 4), TILE_B);
+                // (tagged: the partial of one iteration ago is this wavefront's own store - drained here - and goes out
+                // again under this iteration's epoch bit.  First the sums of iteration it - 1 must be complete, as for a
+                // sweep: that is what says every member has read the partials of it - 1, whose slot the NEXT iteration
+                // overwrites - without it the members of a stopped group run ahead of each other's reduce slices.)
+                if (TG) {
+                    const __amdgpu_buffer_rsrc_t rq =
+                        make_rsrc(a.Vsum + ((size_t)((par ^ 1u) * a.G + g) * W + w) * (TILE_B / 4), TILE_B);
+                    const unsigned tq = ((unsigned)(it - 1) >> 1) & 1u;
+                    for (long spins = 0;;) {
+                        unsigned bad = 0;
 #pragma unroll
-                for (int u = 0; u < MT; ++u) st_sc1(rdst, (u * 64 + lane) * 16u, ld_sc1(rsrc, (u * 64 + lane) * 16u));
+                        for (int u = 0; u < MT; ++u) bad |= tag_bad(ld_sc1(rq, (u * 64 + lane) * 16u), tq);
+                        if (__ballot(bad != 0) == 0) break;
+                        if (poll_gave_up(++spins)) {
+                            if (lane == 0) s_ctl[2] = 1u;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+#pragma unroll
+                for (int u = 0; u < MT; ++u) {
+                    const f32x4 v = ld_sc1(rsrc, (u * 64 + lane) * 16u);
+                    st_sc1(rdst, (u * 64 + lane) * 16u, TG ? tag_set(v, ((unsigned)it >> 1) & 1u) : v);
+                }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the staged block of this task too)
             __syncthreads();
             if (tid == 0) {
-                __hip_atomic_fetch_add(a.done + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!TG) __hip_atomic_fetch_add(a.done + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (!a.static_q) nxt = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s_ctl[0] = nxt;
             }
             __syncthreads();
+            if (TG && s_ctl[2]) {
+                if (tid == 0) __hip_atomic_store(a.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
             continue;
         }
 
@@ -311,8 +397,25 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
             } else if (a.rmode) {
                 const __amdgpu_buffer_rsrc_t rv =
                     make_rsrc(a.Vsum + ((size_t)((par ^ 1u) * a.G + g) * W + w) * (TILE_B / 4), TILE_B);
+                const unsigned tg = ((unsigned)(it - 1) >> 1) & 1u;       // (tagged) epoch bit of the sums of iteration it - 1
+                for (long spins = 0;;) {
 #pragma unroll
-                for (int u = 0; u < MT; ++u) Vin[u] = ld_sc1(rv, (u * 64 + lane) * 16u);
+                    for (int u = 0; u < MT; ++u) Vin[u] = ld_sc1(rv, (u * 64 + lane) * 16u);
+                    if (!TG) break;
+                    unsigned bad = 0;
+#pragma unroll
+                    for (int u = 0; u < MT; ++u) bad |= tag_bad(Vin[u], tg);
+                    if (__ballot(bad != 0) == 0) break;           // every slice of this tile has arrived
+                    if (poll_gave_up(++spins)) {
+                        if (lane == 0) s_ctl[2] = 1u;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (TG) {
+#pragma unroll
+                    for (int u = 0; u < MT; ++u) Vin[u] = tag_clear(Vin[u]);
+                }
             } else {
                 const __amdgpu_buffer_rsrc_t rv =
                     make_rsrc(a.Vpart + ((size_t)((par ^ 1u) * a.G + g) * c) * W * (TILE_B / 4), c * W * TILE_B);
@@ -373,6 +476,10 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                          // block j0 is in stage 0
         WSTAMP(2);
+        if (TG && s_ctl[2]) {                               // the sums of the previous iteration never arrived
+            if (tid == 0) __hip_atomic_store(a.abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
 
         // Every memory operation of a block step gets a whole step to complete: the next block's images and H / P
         // tiles are requested at the top of the step, and the updated tile of the PREVIOUS step is stored there too
@@ -556,17 +663,24 @@ __global__ __launch_bounds__(W * 64, W / 4) void k_fused_wide(WideArgs a) {
             const __amdgpu_buffer_rsrc_t rv =
                 make_rsrc(a.Vpart + (((size_t)(par * a.G + g) * c + e) * W + w) * (TILE_B / 4), TILE_B);
 #pragma unroll
-            for (int u = 0; u < MT; ++u) st_sc1(rv, (u * 64 + lane) * 16u, Vn[u]);
+            for (int u = 0; u < MT; ++u)
+                st_sc1(rv, (u * 64 + lane) * 16u, TG ? tag_set(Vn[u], ((unsigned)it >> 1) & 1u) : Vn[u]);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        if (TG) {
+            // nobody waits for a counter: the partial's floats carry the epoch bit, the H' tiles are read again by this
+            // workgroup only (static schedule), kernels behind the launch see everything
+            lds_barrier();
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
         WSTAMP(4);
         if (tid == 0) {
-            __hip_atomic_fetch_add(a.done + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!TG) __hip_atomic_fetch_add(a.done + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!a.static_q) nxt = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_ctl[0] = nxt;
         }
-        __syncthreads();
+        if (TG) lds_barrier(); else __syncthreads();
         WSTAMP(5);
     }
 }
@@ -657,6 +771,11 @@ __global__ __launch_bounds__(256) void k_wide_err2(WideArgs a, int MT, int W, in
         f32x4 v;
         if (a.rmode) {
             v = (reinterpret_cast<const f32x4*>(a.Vsum) + ((size_t)(par * a.G + g) * W + w) * tile)[u * 64 + lane];
+            if (a.tagged) {                      // (the sums carry their epoch bit: k_fused_wide's readers clear it too)
+                u32x4 b = __builtin_bit_cast(u32x4, v);
+                b = b & ~1u;
+                v = __builtin_bit_cast(f32x4, b);
+            }
         } else {
             const f32x4* p = reinterpret_cast<const f32x4*>(a.Vpart) + ((size_t)(par * a.G + g) * a.c * W + w) * tile;
             v = p[u * 64 + lane];
@@ -734,8 +853,10 @@ WideLayout wide_layout(int M, int N, int T_, int n_cus, int c_req, int w_req) {
     if (c > 64) c = 64;
     f.c = c;
     f.rmode = (c > 8 || (c > 4 && f.G * c <= n_cus)) ? 1 : 0;
+    f.tagged = (f.rmode && f.G * c <= n_cus) ? 1 : 0;
 #ifdef EVC_WIDE_STAMP      // (the stand-alone harness only)
     if (getenv("EVC_WIDE_RMODE_MIN")) f.rmode = c >= atoi(getenv("EVC_WIDE_RMODE_MIN")) ? 1 : 0;
+    if (getenv("EVC_WIDE_NO_TAGS")) f.tagged = 0;
 #endif
     const size_t tile = (size_t)f.MT * 256;      // floats per V tile
     f.aw = (size_t)f.NB * 2 * tile;
@@ -806,6 +927,7 @@ static WideArgs wide_args(const WideLayout& f, const WideBuffers& b, const UttSt
     a.ticket = b.ctl; a.done = b.ctl + 4; a.done_r = b.ctl + 4 + f.G; a.abort = reinterpret_cast<int*>(b.ctl + 1);
     a.frame_utt = u.frame_utt; a.active = u.active; a.h0 = u.h0;
     a.NB = f.NB; a.TT = f.TT; a.G = f.G; a.c = f.c; a.rmode = f.rmode;
+    a.tagged = f.tagged;
     a.N = N; a.T_ = T_; a.mode = mode; a.eps = (float)eps; a.l1 = (float)l1; a.init_const = init_const;
     return a;
 }
@@ -820,11 +942,16 @@ template <int MT, int W>
 static hipError_t wide_launch(const WideArgs& a, unsigned grid, hipStream_t s) {
     const size_t lds = 3 * (size_t)(2 * MT * 1024) + 16;
     if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_wide<MT, W>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = a.tagged ? hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_wide<MT, W, true>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                                : hipFuncSetAttribute(reinterpret_cast<const void*>(&k_fused_wide<MT, W, false>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_fused_wide<MT, W>), dim3(grid), dim3(W * 64), lds, s, a);
+    if (a.tagged)
+        hipLaunchKernelGGL((k_fused_wide<MT, W, true>), dim3(grid), dim3(W * 64), lds, s, a);
+    else
+        hipLaunchKernelGGL((k_fused_wide<MT, W, false>), dim3(grid), dim3(W * 64), lds, s, a);
     return hipGetLastError();
 }
 
@@ -862,6 +989,13 @@ hipError_t wide_iterate(const WideLayout& f, const WideBuffers& b, const UttStat
     // (two 4-wavefront workgroups per CU, one sweeping while the other exchanges, were tried: 90 us per iteration at one
     // utterance against 48 - twice the partial sums to exchange, and the two share the matrix pipe)
     a.static_q = (f.G * f.c <= n_cus && !no_static) ? 1 : 0;
+    a.tagged = (a.static_q && f.tagged) ? 1 : 0;
+    if (a.tagged && it_begin == 0) {
+        // stale floats must not carry the epoch bit of the first two iterations (0): ones everywhere
+        hipError_t em = hipMemsetAsync(b.Vpart, 0xFF, f.vpart * sizeof(float), s);
+        if (em == hipSuccess) em = hipMemsetAsync(b.Vsum, 0xFF, f.vsum * sizeof(float), s);
+        if (em != hipSuccess) return em;
+    }
     const unsigned grid = a.static_q ? (unsigned)(f.G * f.c) : (unsigned)(tasks < n_cus ? tasks : n_cus);
     // the ticket counter of this launch: tickets 0 .. grid-1 belong to the workgroups by index
     hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(b.ctl), (int)grid, 1, s);

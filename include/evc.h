@@ -36,7 +36,7 @@
  *         the solve is redone without any exchange).  EVC_FLAG_NO_EXCHANGE keeps such a call fully
  *         asynchronous (at about half the speed for a lone utterance, ~10 % less for large batches);
  *     (3) evc_nmf_solve / evc_nmf_convert on the task-queue kernels for wide spectra (k_fused_wide: float32,
- *         32 < M <= 208, from one to six utterances on depending on the dictionary size; k_fused_wide64: float64,
+ *         32 < M <= 208, from one utterance (43 frame tiles) on; k_fused_wide64: float64,
  *         176 < M <= 528, 3 .. ~30 utterances, small dictionaries from one):
  *         the same round trip, taken BEFORE anything is written to H or Y, so that a solve whose wait ran out is
  *         redone on the two-contraction path from the untouched inputs (evc_solve_info.redo = 1).  Round 3 delivered
@@ -52,7 +52,9 @@
  *   copied to the device by hipMemcpyAsync from pageable memory, which HIP stages at enqueue time; keep them valid
  *   until the call returns, not longer.
  *   k_fused_all's exchange carries its arrival flag in the lowest mantissa bit of every partial sum it publishes
- *   (readers clear it): each partial V' is truncated by at most one ulp, infinities and NaNs pass unchanged.
+ *   (readers clear it): each partial V' is truncated by at most one ulp, infinities and NaNs pass unchanged.  So does
+ *   k_fused_wide on its static schedule (float32, batches of up to ~5 utterances): one float32 ulp per partial sum and
+ *   per summed slice.
  */
 #ifndef EVC_H
 #define EVC_H

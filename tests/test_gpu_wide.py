@@ -147,14 +147,15 @@ def test_wide_real_audio_golden():
 
 
 def test_routing_by_batch_size():
-    """few frames: the two-contraction path (the task queue's dependency hops cost more than the fusion saves);
-    from about seven utterances on: the fused kernel.  float64 and M <= 32 are not this kernel's."""
+    """fewer frames than one utterance (43 frame tiles): the two-contraction path; from one utterance on: the fused kernel
+    (round 4: static schedule with tagged hand-offs).  M <= 32 is not this kernel's."""
     import exemplars_vc_amd as evc
     o = oracle()
     p = o.synth_problem(201, 256, 4800, seed=1)
     A32, X32 = p["A"].astype(np.float32), p["X"].astype(np.float32)
     kw = dict(iters=3, eps_mode="zero_replace", init="sklearn", info=True)
-    assert evc.solve_activations(A32, X32[:, :688], **kw)[1]["kernel"] == "k_gemm2"
+    assert evc.solve_activations(A32, X32[:, :400], **kw)[1]["kernel"] == "k_gemm2"       # 25 frame tiles
+    assert evc.solve_activations(A32, X32[:, :688], **kw)[1]["kernel"] == "k_fused_wide"  # one utterance (round 4)
     assert evc.solve_activations(A32, X32, **kw)[1]["kernel"] == "k_fused_wide"
     assert evc.solve_activations(A32, X32, fused=False, **kw)[1]["kernel"] == "k_gemm2"
     assert evc.solve_activations(p["A"], p["X"], **kw)[1]["kernel"] == "k_fused_wide64"     # (round 4: 176 < M <= 208 in float64)

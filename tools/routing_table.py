@@ -39,8 +39,8 @@ def main():
            "from these tables; the fractions are of whole calls, so they sit below `bench.py`'s loop-only `roofline.frac`.",
            "",
            "Every row is of the final build of round 4 (first tickets by index, later tickets drawn when a task is finished, static",
-           "schedule for small batches, 8 wavefronts per workgroup, `k_fused_wide64<3>`), except M = 160, which predates the late",
-           "tickets.  An earlier float32 sweep of this round had forced FOUR wavefronts per workgroup at every batch size and",
+           "schedule for small batches - float32 with tagged hand-offs -, 8 wavefronts per workgroup, `k_fused_wide64<3>`), except",
+           "M = 160, which predates the late tickets.  An earlier float32 sweep of this round had forced FOUR wavefronts per workgroup at every batch size and",
            "undervalued the fused kernel at the large batches (16 utterances, M = 201, N = 4096: 0.521 against the 0.69 below);",
            "its lines are kept as `r04_tune_routing_k{20,80}_f32_w4.jsonl`.", ""]
     for k in (80, 20):
