@@ -248,7 +248,7 @@ def cpu_baseline(M, N, K, l1, dtype, seed, T):
     return out, (p, act, Y)
 
 
-def kernel_instance(kernel_tag, M, members, loss):
+def kernel_instance(kernel_tag, M, members, loss, T=None):
     """The template instance the library's routing implies for what evc_solve_info reported (None: not derivable) - the
     string rocprofv3 prints for the kernel, so that a committed PMC summary can be tied to the run."""
     if kernel_tag == "k_fused_all":
@@ -258,8 +258,11 @@ def kernel_instance(kernel_tag, M, members, loss):
     if kernel_tag == "k_fused_wide64":      # whole bin tiles per wavefront (evc_wide64.hip, WIDE64_TPW_SET)
         return "k_fused_wide64<%d>" % next((v for v in (3, 4, 5, 7, 8) if 64 * v + 16 >= M), 8)
     if kernel_tag == "k_fused_wide":        # bin tiles, 8 wavefronts per workgroup (evc_wide.hip, WIDE_MT_SET)
-        # (third argument: tagged hand-offs, the static schedule of batches up to ~5 utterances - not derivable here)
-        return "k_fused_wide<%d, 8, false>" % next((v for v in (4, 6, 8, 10, 13) if 16 * v >= M), 13)
+        # third argument: tagged hand-offs = the static schedule with reduce slices (wide_layout: more than four ranges
+        # and no more sweep tasks per iteration than the 256 CUs)
+        groups = -(-(-(-T // 16)) // 8) if T else 0
+        tagged = bool(T) and members is not None and members > 4 and groups * members <= 256
+        return "k_fused_wide<%d, 8, %s>" % (next((v for v in (4, 6, 8, 10, 13) if 16 * v >= M), 13), "true" if tagged else "false")
     return None
 
 
@@ -269,7 +272,7 @@ def pmc_traffic(kernel_tag, M, N, K, T, dtype, members=None, loss="frobenius"):
     value says whether the summary's kernel instance (template arguments included) is the one this run reports - a
     summary of another instance or of an older build of the kernel is still shown, but flagged."""
     import glob
-    want = kernel_instance(kernel_tag, M, members, loss)
+    want = kernel_instance(kernel_tag, M, members, loss, T)
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc*.json")), reverse=True):
         try:
             pm = json.load(open(path))

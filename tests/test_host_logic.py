@@ -99,3 +99,23 @@ def test_partition_is_a_balanced_partition(n):
     assert max(loads) - min(loads) <= max(lens)
     assert partition_utterances(lens, n) == parts          # deterministic
     assert partition_utterances([], n) == [[] for _ in range(n)]
+
+
+def test_bench_names_the_kernel_instance_a_pmc_summary_must_be_of():
+    """bench.py ties a committed rocprofv3 PMC summary to a run by the kernel's template instance (roofline.traffic_run_match):
+    the instance names follow the library's routing (evc_fused_all.hip pick_c, wide_layout / wide64_layout)."""
+    import importlib
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    bench = importlib.import_module("bench")
+    assert bench.kernel_instance("k_fused_all", 25, 8, "frobenius") == "k_fused_all<7, 0, false>"
+    assert bench.kernel_instance("k_fused_all", 25, 1, "kl") == "k_fused_all<7, 1, true>"
+    # k_fused_wide: 8 wavefronts; tagged hand-offs = static schedule with reduce slices (1 and 2 utterances of 688 frames)
+    assert bench.kernel_instance("k_fused_wide", 201, 42, "frobenius", 688) == "k_fused_wide<13, 8, true>"
+    assert bench.kernel_instance("k_fused_wide", 201, 23, "frobenius", 1376) == "k_fused_wide<13, 8, true>"
+    assert bench.kernel_instance("k_fused_wide", 201, 8, "frobenius", 4128) == "k_fused_wide<13, 8, false>"
+    assert bench.kernel_instance("k_fused_wide", 64, 3, "frobenius", 11008) == "k_fused_wide<4, 8, false>"
+    assert bench.kernel_instance("k_fused_wide64", 513, 1, "frobenius", 11008) == "k_fused_wide64<8>"
+    assert bench.kernel_instance("k_fused_wide64", 201, 1, "frobenius", 11008) == "k_fused_wide64<3>"
+    assert bench.kernel_instance("k_gemm2", 201, 1, "frobenius") is None
