@@ -100,6 +100,30 @@ def test_wide_l1_and_the_stop_rule_per_utterance():
     check(Hl, act)
 
 
+def test_wide_stopped_frame_groups_keep_step_with_the_others():
+    """Round 4, tagged hand-offs on the static schedule: the wavefronts of a frame group whose utterances have all stopped
+    republish their partial sums without sweeping, and must still wait for the previous iteration's sums - without that
+    the members of such a group ran ahead of each other's reduce slices, the bounded polls ran out and the solve was redone
+    on the two contractions (found by tools/soak_wide.py).  Four utterances of 8 frame tiles each = one frame group each;
+    two are a scaled dictionary atom plus a little of another (they converge at the first checks), two are ordinary."""
+    import exemplars_vc_amd as evc
+    o = oracle()
+    p = o.synth_problem(201, 768, 512, seed=31)
+    W_rows = np.ascontiguousarray(p["A"].T).astype(np.float32)
+    X_rows = np.ascontiguousarray(p["X"].T).astype(np.float32)
+    for a, atom in ((128, 5), (384, 77)):
+        X_rows[a:a + 128] = (0.7 * W_rows[atom] + 0.05 * W_rows[atom + 1])[None, :]
+    offs = [0, 128, 256, 384, 512]
+    kw = dict(layout="frame_major", iters=120, eps_mode="zero_replace", init="sklearn", check_every=5, stop_rule="sklearn",
+              tol=2e-3, utt_offsets=offs, info=True)
+    H, info = evc.solve_activations(W_rows, X_rows, fused_w=8, **kw)       # (32 frame tiles: below the routing's 43)
+    Hr, info_r = evc.solve_activations(W_rows, X_rows, fused=False, **kw)
+    assert info["kernel"] == "k_fused_wide" and info["redo"] == 0 and info["members"] > 4, info
+    assert list(info["n_iter"]) == list(info_r["n_iter"]), (info["n_iter"], info_r["n_iter"])
+    assert int(min(info["n_iter"])) < int(max(info["n_iter"])), info["n_iter"]       # somebody stopped early
+    np.testing.assert_allclose(H, Hr, rtol=2e-3, atol=2e-6 * float(Hr.max()))
+
+
 def test_wide_kl():
     import exemplars_vc_amd as evc
     o = oracle()
